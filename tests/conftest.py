@@ -1,0 +1,24 @@
+"""pytest configuration: markers and import paths.
+
+`-m "not gpu"`: oracle vs the reference's golden vectors, host logic, C-ABI
+symbol/loader checks, gloo multi-process sharding.  `-m gpu`: parity tests
+proper — the HIP path, called through the C-ABI, against the oracle.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "erased-cells_amd", "python"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
