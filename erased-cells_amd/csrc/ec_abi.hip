@@ -1,0 +1,668 @@
+// ec_abi.hip — the extern "C" surface of liberased_cells_hip.so (include/erased_cells.h):
+// runtime (device, memory, errors), the type lattice, and the type-erased
+// dispatch of every kernel family except the four binary ops (ec_binop_*.hip).
+//
+// There is no CPU fallback anywhere in this library: without a HIP device every
+// compute entry point returns EC_ERR_HIP / EC_ERR_NOT_INITIALIZED.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "ec_lattice.hpp"
+#include "ec_map_kernels.hpp"
+#include "ec_reduce_kernels.hpp"
+#include "ec_runtime.hpp"
+
+namespace ecd {
+
+// ------------------------------------------------------------------ state
+static thread_local std::string t_err;
+static thread_local int t_narrow_src = -1, t_narrow_dst = -1;
+
+static std::mutex g_mu;
+static bool g_inited = false;
+static int g_device = -1;
+static int g_cus = 256;
+static Tuning g_tuning;
+static std::map<hipStream_t, Scratch> g_scratch;
+
+Tuning& tuning() { return g_tuning; }
+int device_cus() { return g_cus; }
+
+ec_status set_error(ec_status code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    t_err = buf;
+    return code;
+}
+
+ec_status set_narrowing(int src, int dst) {
+    static const char* names[EC_NTYPES] = {"UInt8", "UInt16", "UInt32", "UInt64", "Int8",
+                                           "Int16", "Int32", "Int64", "Float32", "Float64"};
+    t_narrow_src = src;
+    t_narrow_dst = dst;
+    // message text of Error::NarrowingError (src/error.rs:14)
+    return set_error(EC_ERR_NARROWING, "Invalid narrowing from cell-type %s to %s", names[src], names[dst]);
+}
+
+ec_status check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return EC_OK;
+    return set_error(EC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+ec_status check_launch(const char* what) { return check_hip(hipGetLastError(), what); }
+
+static ec_status ensure_init() {
+    if (g_inited) return EC_OK;
+    return set_error(EC_ERR_NOT_INITIALIZED, "ec_init() has not been called (no HIP device bound)");
+}
+
+ec_status get_scratch(hipStream_t s, Scratch* out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_scratch.find(s);
+    if (it == g_scratch.end()) {
+        Scratch sc;
+        ec_status st = check_hip(hipMalloc(reinterpret_cast<void**>(&sc.dev), (2 * kMaxReduceBlocks + 4) * sizeof(int64_t)),
+                                 "hipMalloc(scratch)");
+        if (st != EC_OK) return st;
+        st = check_hip(hipHostMalloc(reinterpret_cast<void**>(&sc.host), 4 * sizeof(int64_t), hipHostMallocDefault),
+                       "hipHostMalloc(scratch)");
+        if (st != EC_OK) { (void)hipFree(sc.dev); return st; }
+        it = g_scratch.emplace(s, sc).first;
+    }
+    *out = it->second;
+    return EC_OK;
+}
+
+static inline hipStream_t S(ec_stream s) { return static_cast<hipStream_t>(s); }
+
+template <typename Fn>
+static ec_status launch_map(const Fn& fn, size_t n, bool aligned, hipStream_t s, const char* what) {
+    if (n == 0) return EC_OK;
+    if (!aligned) {
+        k_map_cellwise<Fn><<<grid_for((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fn, n);
+    } else {
+        const size_t groups = n / Fn::CPL;
+        const size_t tiles = (groups + size_t(kBlock) * kMapU - 1) / (size_t(kBlock) * kMapU);
+        k_map<Fn, kMapU><<<grid_for(tiles, g_tuning.bpc), kBlock, 0, s>>>(fn, n);
+    }
+    return check_launch(what);
+}
+
+// ------------------------------------------------------------------ convert
+template <typename Sx, typename Dx>
+static ec_status launch_convert(const void* src, void* dst, size_t n, hipStream_t s) {
+    if constexpr (ecl::can_fit_into(ecl::dtype_of<Sx>::value, ecl::dtype_of<Dx>::value) &&
+                  ecl::dtype_of<Sx>::value != ecl::dtype_of<Dx>::value) {
+        ConvertFn<Sx, Dx> fn{static_cast<const Sx*>(src), static_cast<Dx*>(dst)};
+        return launch_map(fn, n, aligned16(src, dst, dst), s, "convert");
+    } else {
+        (void)src; (void)dst; (void)n; (void)s;
+        return set_error(EC_ERR_ARG, "convert: pair not instantiated");
+    }
+}
+
+static ec_status dispatch_convert(int st, const void* src, int dt, void* dst, size_t n, hipStream_t s) {
+#define EC_ROW(SID, ST)                                                      \
+    case SID:                                                                \
+        switch (dt) {                                                        \
+            case EC_U8: return launch_convert<ST, uint8_t>(src, dst, n, s);  \
+            case EC_U16: return launch_convert<ST, uint16_t>(src, dst, n, s); \
+            case EC_U32: return launch_convert<ST, uint32_t>(src, dst, n, s); \
+            case EC_U64: return launch_convert<ST, uint64_t>(src, dst, n, s); \
+            case EC_I8: return launch_convert<ST, int8_t>(src, dst, n, s);   \
+            case EC_I16: return launch_convert<ST, int16_t>(src, dst, n, s); \
+            case EC_I32: return launch_convert<ST, int32_t>(src, dst, n, s); \
+            case EC_I64: return launch_convert<ST, int64_t>(src, dst, n, s); \
+            case EC_F32: return launch_convert<ST, float>(src, dst, n, s);   \
+            case EC_F64: return launch_convert<ST, double>(src, dst, n, s);  \
+        }                                                                    \
+        break;
+    switch (st) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "convert: bad dtype");
+}
+
+// ------------------------------------------------------------------ min/max
+template <typename T>
+static ec_status launch_min_max(const void* p, const uint8_t* mask, size_t n, int64_t* keys2_dev, hipStream_t s) {
+    Scratch sc;
+    ec_status st = get_scratch(s, &sc);
+    if (st != EC_OK) return st;
+    const T* tp = static_cast<const T*>(p);
+    unsigned grid = 0;
+    if (n > 0) {
+        const bool al = aligned16(p, p, p) && (!mask || (reinterpret_cast<uintptr_t>(mask) % (16 / sizeof(T))) == 0);
+        int cap = g_cus * g_tuning.reduce_bpc;
+        if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
+        if (al) {
+            const size_t groups = n / (16 / sizeof(T));
+            size_t tiles = (groups + size_t(kBlock) * kReduceU - 1) / (size_t(kBlock) * kReduceU);
+            if (tiles < 1) tiles = 1;
+            grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
+            if (mask) k_min_max_partials<T, true, kReduceU><<<grid, kBlock, 0, s>>>(tp, mask, n, sc.dev);
+            else k_min_max_partials<T, false, kReduceU><<<grid, kBlock, 0, s>>>(tp, nullptr, n, sc.dev);
+        } else {
+            size_t blocks = (n + kBlock - 1) / kBlock;
+            grid = static_cast<unsigned>(blocks < size_t(cap) ? blocks : size_t(cap));
+            if (mask) k_min_max_partials_cellwise<T, true><<<grid, kBlock, 0, s>>>(tp, mask, n, sc.dev);
+            else k_min_max_partials_cellwise<T, false><<<grid, kBlock, 0, s>>>(tp, nullptr, n, sc.dev);
+        }
+        st = check_launch("min_max(partials)");
+        if (st != EC_OK) return st;
+    }
+    // sentinels (T::MAX, T::MIN): src/buffer.rs:170, finite for floats (src/ctype.rs:158-179)
+    k_min_max_finalize<<<1, kBlock, 0, s>>>(sc.dev, static_cast<int>(grid), order_key<T>(Limits<T>::hi),
+                                            order_key<T>(Limits<T>::lo), keys2_dev);
+    return check_launch("min_max(finalize)");
+}
+
+static ec_status dispatch_min_max(int t, const void* p, const uint8_t* mask, size_t n, int64_t* keys2_dev, hipStream_t s) {
+#define EC_ROW(ID, T) case ID: return launch_min_max<T>(p, mask, n, keys2_dev, s);
+    switch (t) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "min_max: bad dtype");
+}
+
+template <typename T>
+static void decode_keys(const int64_t keys2[2], ec_value* mn, ec_value* mx) {
+    T a = key_value<T>(~keys2[0]), b = key_value<T>(keys2[1]);
+    std::memset(mn, 0, sizeof *mn);
+    std::memset(mx, 0, sizeof *mx);
+    mn->dtype = mx->dtype = static_cast<uint8_t>(ecl::dtype_of<T>::value);
+    std::memcpy(&mn->v, &a, sizeof a);
+    std::memcpy(&mx->v, &b, sizeof b);
+}
+
+}  // namespace ecd
+
+using namespace ecd;
+
+// =================================================================== lattice
+extern "C" ec_dtype ec_union(ec_dtype a, ec_dtype b) {
+    return (ecl::valid(a) && ecl::valid(b)) ? static_cast<ec_dtype>(ecl::union_of(a, b)) : static_cast<ec_dtype>(EC_F64);
+}
+extern "C" int32_t ec_can_fit_into(ec_dtype src, ec_dtype dst) {
+    return ecl::valid(src) && ecl::valid(dst) && ecl::can_fit_into(src, dst);
+}
+extern "C" size_t ec_size_of(ec_dtype t) { return ecl::size_of(t); }
+extern "C" ec_dtype ec_neg_result_type(ec_dtype t) { return static_cast<ec_dtype>(ecl::neg_result(t)); }
+
+template <typename T>
+static void put_value(ec_value* out, int dtype, T x) {
+    std::memset(out, 0, sizeof *out);
+    out->dtype = static_cast<uint8_t>(dtype);
+    std::memcpy(&out->v, &x, sizeof x);
+}
+
+extern "C" ec_status ec_min_value(ec_dtype t, ec_value* out) {
+    if (!out) return set_error(EC_ERR_ARG, "ec_min_value: null out");
+#define EC_ROW(ID, T) case ID: put_value<T>(out, ID, Limits<T>::lo); return EC_OK;
+    switch (t) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_min_value: bad dtype %d", int(t));
+}
+extern "C" ec_status ec_max_value(ec_dtype t, ec_value* out) {
+    if (!out) return set_error(EC_ERR_ARG, "ec_max_value: null out");
+#define EC_ROW(ID, T) case ID: put_value<T>(out, ID, Limits<T>::hi); return EC_OK;
+    switch (t) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_max_value: bad dtype %d", int(t));
+}
+extern "C" ec_status ec_nodata_default(ec_dtype t, ec_value* out) {
+    if (!out) return set_error(EC_ERR_ARG, "ec_nodata_default: null out");
+    if (t == EC_F32) { put_value<uint32_t>(out, t, 0x7fc00000u); return EC_OK; }           // f32::NAN
+    if (t == EC_F64) { put_value<uint64_t>(out, t, 0x7ff8000000000000ull); return EC_OK; }  // f64::NAN
+    return ec_min_value(t, out);                                                            // <int>::MIN
+}
+
+template <typename T>
+static double value_as_f64(const ec_value* v) { T x; std::memcpy(&x, &v->v, sizeof x); return static_cast<double>(x); }
+
+extern "C" double ec_value_to_f64(const ec_value* v) {
+    if (!v) return 0.0;
+#define EC_ROW(ID, T) case ID: return value_as_f64<T>(v);
+    switch (v->dtype) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return 0.0;
+}
+
+template <typename Sx, typename Dx>
+static void value_cast(const ec_value* v, ec_value* out) {
+    Sx x; std::memcpy(&x, &v->v, sizeof x);
+    put_value<Dx>(out, ecl::dtype_of<Dx>::value, static_cast<Dx>(x));
+}
+
+extern "C" ec_status ec_value_convert(const ec_value* v, ec_dtype dst, ec_value* out) {
+    if (!v || !out) return set_error(EC_ERR_ARG, "ec_value_convert: null argument");
+    if (!ecl::valid(v->dtype) || !ecl::valid(dst)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_value_convert: bad dtype");
+    if (!ecl::can_fit_into(v->dtype, dst)) return set_narrowing(v->dtype, dst);  // value.rs:79-81
+    if (v->dtype == dst) { *out = *v; return EC_OK; }                            // value.rs:83-85
+#define EC_ROW(SID, ST)                                                \
+    case SID:                                                          \
+        switch (dst) {                                                 \
+            case EC_U8: value_cast<ST, uint8_t>(v, out); return EC_OK; \
+            case EC_U16: value_cast<ST, uint16_t>(v, out); return EC_OK; \
+            case EC_U32: value_cast<ST, uint32_t>(v, out); return EC_OK; \
+            case EC_U64: value_cast<ST, uint64_t>(v, out); return EC_OK; \
+            case EC_I8: value_cast<ST, int8_t>(v, out); return EC_OK;  \
+            case EC_I16: value_cast<ST, int16_t>(v, out); return EC_OK; \
+            case EC_I32: value_cast<ST, int32_t>(v, out); return EC_OK; \
+            case EC_I64: value_cast<ST, int64_t>(v, out); return EC_OK; \
+            case EC_F32: value_cast<ST, float>(v, out); return EC_OK;  \
+            case EC_F64: value_cast<ST, double>(v, out); return EC_OK; \
+        }                                                              \
+        break;
+    switch (v->dtype) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_value_convert: bad dtype");
+}
+
+extern "C" ec_status ec_shard_range(uint64_t n_rows, uint64_t n_cols, uint32_t shard, uint32_t n_shards,
+                                    uint64_t* cell_offset, uint64_t* cell_len) {
+    if (!cell_offset || !cell_len || n_shards == 0 || shard >= n_shards)
+        return set_error(EC_ERR_ARG, "ec_shard_range: shard %u of %u", shard, n_shards);
+    const uint64_t q = n_rows / n_shards, rem = n_rows % n_shards;
+    const uint64_t row0 = uint64_t(shard) * q + (shard < rem ? shard : rem);
+    const uint64_t rows = q + (shard < rem ? 1 : 0);
+    *cell_offset = row0 * n_cols;
+    *cell_len = rows * n_cols;
+    return EC_OK;
+}
+
+// =================================================================== runtime
+extern "C" int32_t ec_abi_version(void) { return EC_ABI_VERSION; }
+
+extern "C" ec_status ec_init(int32_t device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_inited && g_device == device) return EC_OK;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_error(EC_ERR_HIP, "ec_init: no HIP device (%s)", e == hipSuccess ? "count == 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return set_error(EC_ERR_ARG, "ec_init: device %d of %d", device, count);
+    ec_status st = check_hip(hipSetDevice(device), "hipSetDevice");
+    if (st != EC_OK) return st;
+    hipDeviceProp_t prop;
+    st = check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    if (st != EC_OK) return st;
+    g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_device = device;
+    g_inited = true;
+    return EC_OK;
+}
+
+extern "C" ec_status ec_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_scratch) {
+        (void)hipFree(kv.second.dev);
+        (void)hipHostFree(kv.second.host);
+    }
+    g_scratch.clear();
+    g_inited = false;
+    g_device = -1;
+    return EC_OK;
+}
+
+extern "C" const char* ec_last_error_string(void) { return t_err.c_str(); }
+
+extern "C" ec_status ec_last_narrowing(ec_dtype* src, ec_dtype* dst) {
+    if (!src || !dst || t_narrow_src < 0) return set_error(EC_ERR_ARG, "ec_last_narrowing: nothing recorded");
+    *src = static_cast<ec_dtype>(t_narrow_src);
+    *dst = static_cast<ec_dtype>(t_narrow_dst);
+    return EC_OK;
+}
+
+extern "C" ec_status ec_device_info(int32_t* n_cu, uint64_t* hbm_bytes, char* name, size_t name_cap) {
+    ec_status st = ensure_init();
+    if (st != EC_OK) return st;
+    hipDeviceProp_t prop;
+    st = check_hip(hipGetDeviceProperties(&prop, g_device), "hipGetDeviceProperties");
+    if (st != EC_OK) return st;
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    if (name && name_cap) { std::strncpy(name, prop.gcnArchName, name_cap - 1); name[name_cap - 1] = 0; }
+    return EC_OK;
+}
+
+extern "C" ec_status ec_alloc(void** dptr, size_t bytes) {
+    if (!dptr) return set_error(EC_ERR_ARG, "ec_alloc: null out pointer");
+    ec_status st = ensure_init();
+    if (st != EC_OK) return st;
+    *dptr = nullptr;
+    if (bytes == 0) return EC_OK;
+    return check_hip(hipMalloc(dptr, bytes), "hipMalloc");
+}
+extern "C" ec_status ec_free(void* dptr) { return dptr ? check_hip(hipFree(dptr), "hipFree") : EC_OK; }
+
+extern "C" ec_status ec_upload(void* dst_dev, const void* src_host, size_t bytes, ec_stream stream) {
+    if (bytes == 0) return EC_OK;
+    if (!dst_dev || !src_host) return set_error(EC_ERR_ARG, "ec_upload: null pointer");
+    ec_status st = check_hip(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, S(stream)), "hipMemcpyAsync(H2D)");
+    if (st != EC_OK) return st;
+    return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");  // src_host may be pageable
+}
+extern "C" ec_status ec_download(void* dst_host, const void* src_dev, size_t bytes, ec_stream stream) {
+    if (bytes == 0) return EC_OK;
+    if (!dst_host || !src_dev) return set_error(EC_ERR_ARG, "ec_download: null pointer");
+    ec_status st = check_hip(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync(D2H)");
+    if (st != EC_OK) return st;
+    return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+}
+extern "C" ec_status ec_copy(void* dst_dev, const void* src_dev, size_t bytes, ec_stream stream) {
+    if (bytes == 0) return EC_OK;
+    if (!dst_dev || !src_dev) return set_error(EC_ERR_ARG, "ec_copy: null pointer");
+    return check_hip(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, S(stream)), "hipMemcpyAsync(D2D)");
+}
+extern "C" ec_status ec_stream_create(ec_stream* out) {
+    if (!out) return set_error(EC_ERR_ARG, "ec_stream_create: null out");
+    ec_status st = ensure_init();
+    if (st != EC_OK) return st;
+    hipStream_t s;
+    st = check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    if (st == EC_OK) *out = s;
+    return st;
+}
+extern "C" ec_status ec_stream_destroy(ec_stream s) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_scratch.find(S(s));
+        if (it != g_scratch.end()) {
+            (void)hipFree(it->second.dev);
+            (void)hipHostFree(it->second.host);
+            g_scratch.erase(it);
+        }
+    }
+    return check_hip(hipStreamDestroy(S(s)), "hipStreamDestroy");
+}
+extern "C" ec_status ec_stream_sync(ec_stream s) { return check_hip(hipStreamSynchronize(S(s)), "hipStreamSynchronize"); }
+
+extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
+    if (!key) return set_error(EC_ERR_ARG, "ec_tune_set: null key");
+    if (!std::strcmp(key, "binop_variant")) g_tuning.binop_variant = static_cast<int>(value);
+    else if (!std::strcmp(key, "bpc")) g_tuning.bpc = static_cast<int>(value);
+    else if (!std::strcmp(key, "reduce_bpc")) g_tuning.reduce_bpc = value > 0 ? static_cast<int>(value) : 8;
+    else return set_error(EC_ERR_ARG, "ec_tune_set: unknown key '%s'", key);
+    return EC_OK;
+}
+
+// =================================================================== arithmetic
+#define EC_REQUIRE_INIT()               \
+    do {                                \
+        ec_status st_ = ensure_init();  \
+        if (st_ != EC_OK) return st_;   \
+    } while (0)
+
+extern "C" ec_status ec_binop(ec_op op, ec_dtype lt, const void* l, ec_dtype rt, const void* r, size_t n, double* out,
+                              ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (n == 0) return EC_OK;
+    if (!l || !r || !out) return set_error(EC_ERR_ARG, "ec_binop: null pointer");
+    switch (op) {
+        case EC_ADD: return dispatch_binop<EC_ADD>(lt, l, rt, r, n, out, S(stream));
+        case EC_SUB: return dispatch_binop<EC_SUB>(lt, l, rt, r, n, out, S(stream));
+        case EC_MUL: return dispatch_binop<EC_MUL>(lt, l, rt, r, n, out, S(stream));
+        case EC_DIV: return dispatch_binop<EC_DIV>(lt, l, rt, r, n, out, S(stream));
+    }
+    return set_error(EC_ERR_ARG, "ec_binop: bad op %d", int(op));
+}
+
+extern "C" ec_status ec_binop_scalar(ec_op op, ec_dtype lt, const void* l, size_t n, const ec_value* rhs, double* out,
+                                     ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!rhs || !ecl::valid(rhs->dtype)) return set_error(EC_ERR_ARG, "ec_binop_scalar: bad rhs");
+    if (n == 0) return EC_OK;
+    if (!l || !out) return set_error(EC_ERR_ARG, "ec_binop_scalar: null pointer");
+    // unify + to_f64 of the scalar (value.rs:206-207) happens once, here
+    const double s = ec_value_to_f64(rhs);
+    switch (op) {
+        case EC_ADD: return dispatch_binop_scalar<EC_ADD>(lt, l, s, n, out, S(stream));
+        case EC_SUB: return dispatch_binop_scalar<EC_SUB>(lt, l, s, n, out, S(stream));
+        case EC_MUL: return dispatch_binop_scalar<EC_MUL>(lt, l, s, n, out, S(stream));
+        case EC_DIV: return dispatch_binop_scalar<EC_DIV>(lt, l, s, n, out, S(stream));
+    }
+    return set_error(EC_ERR_ARG, "ec_binop_scalar: bad op %d", int(op));
+}
+
+extern "C" ec_status ec_masked_binop(ec_op op, ec_dtype lt, const void* l, const uint8_t* lmask, ec_dtype rt, const void* r,
+                                     const uint8_t* rmask, size_t n, double* out, uint8_t* out_mask, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (n == 0) return EC_OK;
+    if (!l || !r || !out || !lmask || !rmask || !out_mask) return set_error(EC_ERR_ARG, "ec_masked_binop: null pointer");
+    switch (op) {
+        case EC_ADD: return dispatch_masked_binop<EC_ADD>(lt, l, lmask, rt, r, rmask, n, out, out_mask, S(stream));
+        case EC_SUB: return dispatch_masked_binop<EC_SUB>(lt, l, lmask, rt, r, rmask, n, out, out_mask, S(stream));
+        case EC_MUL: return dispatch_masked_binop<EC_MUL>(lt, l, lmask, rt, r, rmask, n, out, out_mask, S(stream));
+        case EC_DIV: return dispatch_masked_binop<EC_DIV>(lt, l, lmask, rt, r, rmask, n, out, out_mask, S(stream));
+    }
+    return set_error(EC_ERR_ARG, "ec_masked_binop: bad op %d", int(op));
+}
+
+extern "C" ec_status ec_neg(ec_dtype t, const void* in, size_t n, void* out, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!ecl::valid(t)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_neg: bad dtype %d", int(t));
+    if (n == 0) return EC_OK;
+    if (!in || !out) return set_error(EC_ERR_ARG, "ec_neg: null pointer");
+#define EC_ROW(ID, T)                                                                             \
+    case ID: {                                                                                    \
+        NegFn<T> fn{static_cast<const T*>(in), static_cast<typename NegOut<T>::type*>(out)};      \
+        return launch_map(fn, n, aligned16(in, out, out), S(stream), "neg");                      \
+    }
+    switch (t) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return EC_OK;
+}
+
+extern "C" ec_status ec_convert(ec_dtype st, const void* src, ec_dtype dt, void* dst, size_t n, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!ecl::valid(st) || !ecl::valid(dt)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_convert: bad dtype");
+    if (!ecl::can_fit_into(st, dt)) return set_narrowing(st, dt);  // buffer.rs:157-159: before touching data
+    if (n == 0) return EC_OK;
+    if (!src || !dst) return set_error(EC_ERR_ARG, "ec_convert: null pointer");
+    if (st == dt) return ec_copy(dst, src, n * ecl::size_of(st), stream);  // buffer.rs:151-153
+    return dispatch_convert(st, src, dt, dst, n, S(stream));
+}
+
+template <typename W>
+static ec_status fill_w(void* dst, size_t n, const ec_value* v, hipStream_t s) {
+    W w; std::memcpy(&w, &v->v, sizeof w);
+    FillFn<W> fn{static_cast<W*>(dst), w};
+    return launch_map(fn, n, aligned16(dst, dst, dst), s, "fill");
+}
+
+extern "C" ec_status ec_fill(ec_dtype t, void* dst, size_t n, const ec_value* value, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!ecl::valid(t) || !value || value->dtype != t) return set_error(EC_ERR_ARG, "ec_fill: value dtype must equal t");
+    if (n == 0) return EC_OK;
+    if (!dst) return set_error(EC_ERR_ARG, "ec_fill: null pointer");
+    switch (ecl::size_of(t)) {
+        case 1: return fill_w<uint8_t>(dst, n, value, S(stream));
+        case 2: return fill_w<uint16_t>(dst, n, value, S(stream));
+        case 4: return fill_w<uint32_t>(dst, n, value, S(stream));
+        default: return fill_w<uint64_t>(dst, n, value, S(stream));
+    }
+}
+
+// =================================================================== min/max
+extern "C" ec_status ec_min_max_keys(ec_dtype t, const void* p, const uint8_t* mask_or_null, size_t n, int64_t* keys2_dev,
+                                     ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!keys2_dev || (n > 0 && !p)) return set_error(EC_ERR_ARG, "ec_min_max_keys: null pointer");
+    return dispatch_min_max(t, p, mask_or_null, n, keys2_dev, S(stream));
+}
+
+extern "C" ec_status ec_min_max_decode(ec_dtype t, const int64_t keys2_host[2], ec_value* mn, ec_value* mx) {
+    if (!keys2_host || !mn || !mx) return set_error(EC_ERR_ARG, "ec_min_max_decode: null pointer");
+#define EC_ROW(ID, T) case ID: decode_keys<T>(keys2_host, mn, mx); return EC_OK;
+    switch (t) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_min_max_decode: bad dtype %d", int(t));
+}
+
+extern "C" ec_status ec_min_max(ec_dtype t, const void* p, const uint8_t* mask_or_null, size_t n, ec_value* mn, ec_value* mx,
+                                ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!mn || !mx || (n > 0 && !p)) return set_error(EC_ERR_ARG, "ec_min_max: null pointer");
+    Scratch sc;
+    ec_status st = get_scratch(S(stream), &sc);
+    if (st != EC_OK) return st;
+    st = dispatch_min_max(t, p, mask_or_null, n, sc.dev_result(), S(stream));
+    if (st != EC_OK) return st;
+    st = check_hip(hipMemcpyAsync(sc.host, sc.dev_result(), 2 * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync");
+    if (st != EC_OK) return st;
+    st = check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+    if (st != EC_OK) return st;
+    return ec_min_max_decode(t, sc.host, mn, mx);
+}
+
+// =================================================================== masks
+template <typename W>
+static ec_status mask_from_nd_w(const void* p, size_t n, const ec_value* nd, uint8_t* mask, hipStream_t s) {
+    W w; std::memcpy(&w, &nd->v, sizeof w);
+    MaskFromNodataFn<W> fn{static_cast<const W*>(p), mask, w};
+    const bool al = aligned16(p, p, p) && (reinterpret_cast<uintptr_t>(mask) % (16 / sizeof(W))) == 0;
+    return launch_map(fn, n, al, s, "mask_from_nodata");
+}
+
+extern "C" ec_status ec_mask_from_nodata(ec_dtype t, const void* p, size_t n, const ec_value* nd_or_null, uint8_t* mask,
+                                         ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!ecl::valid(t)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_mask_from_nodata: bad dtype %d", int(t));
+    if (nd_or_null && nd_or_null->dtype != t) return set_error(EC_ERR_ARG, "ec_mask_from_nodata: nodata dtype must equal t");
+    if (n == 0) return EC_OK;
+    if (!p || !mask) return set_error(EC_ERR_ARG, "ec_mask_from_nodata: null pointer");
+    if (!nd_or_null)  // NoData::None: nothing matches (nodata.rs:43-48) -> all true
+        return check_hip(hipMemsetAsync(mask, 1, n, S(stream)), "hipMemsetAsync");
+    switch (ecl::size_of(t)) {
+        case 1: return mask_from_nd_w<uint8_t>(p, n, nd_or_null, mask, S(stream));
+        case 2: return mask_from_nd_w<uint16_t>(p, n, nd_or_null, mask, S(stream));
+        case 4: return mask_from_nd_w<uint32_t>(p, n, nd_or_null, mask, S(stream));
+        default: return mask_from_nd_w<uint64_t>(p, n, nd_or_null, mask, S(stream));
+    }
+}
+
+template <typename W>
+static ec_status mask_select_w(const void* p, const uint8_t* mask, size_t n, const ec_value* nd, void* out, hipStream_t s) {
+    W w; std::memcpy(&w, &nd->v, sizeof w);
+    MaskSelectFn<W> fn{static_cast<const W*>(p), mask, static_cast<W*>(out), w};
+    const bool al = aligned16(p, out, out) && (reinterpret_cast<uintptr_t>(mask) % (16 / sizeof(W))) == 0;
+    return launch_map(fn, n, al, s, "mask_select");
+}
+
+extern "C" ec_status ec_mask_select(ec_dtype t, const void* p, const uint8_t* mask, size_t n, const ec_value* nd_or_null,
+                                    void* out, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!ecl::valid(t)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_mask_select: bad dtype %d", int(t));
+    if (nd_or_null && nd_or_null->dtype != t) return set_error(EC_ERR_ARG, "ec_mask_select: nodata dtype must equal t");
+    if (n == 0) return EC_OK;
+    if (!p || !out) return set_error(EC_ERR_ARG, "ec_mask_select: null pointer");
+    if (!nd_or_null) return ec_copy(out, p, n * ecl::size_of(t), stream);  // masked_buffer.rs:149-151
+    if (!mask) return set_error(EC_ERR_ARG, "ec_mask_select: null mask");
+    switch (ecl::size_of(t)) {
+        case 1: return mask_select_w<uint8_t>(p, mask, n, nd_or_null, out, S(stream));
+        case 2: return mask_select_w<uint16_t>(p, mask, n, nd_or_null, out, S(stream));
+        case 4: return mask_select_w<uint32_t>(p, mask, n, nd_or_null, out, S(stream));
+        default: return mask_select_w<uint64_t>(p, mask, n, nd_or_null, out, S(stream));
+    }
+}
+
+extern "C" ec_status ec_mask_and(const uint8_t* l, const uint8_t* r, size_t n, uint8_t* out, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (n == 0) return EC_OK;
+    if (!l || !r || !out) return set_error(EC_ERR_ARG, "ec_mask_and: null pointer");
+    MaskBin<0> fn{l, r, out};
+    return launch_map(fn, n, aligned16(l, r, out), S(stream), "mask_and");
+}
+extern "C" ec_status ec_mask_or(const uint8_t* l, const uint8_t* r, size_t n, uint8_t* out, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (n == 0) return EC_OK;
+    if (!l || !r || !out) return set_error(EC_ERR_ARG, "ec_mask_or: null pointer");
+    MaskBin<1> fn{l, r, out};
+    return launch_map(fn, n, aligned16(l, r, out), S(stream), "mask_or");
+}
+extern "C" ec_status ec_mask_not(const uint8_t* m, size_t n, uint8_t* out, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (n == 0) return EC_OK;
+    if (!m || !out) return set_error(EC_ERR_ARG, "ec_mask_not: null pointer");
+    MaskNot fn{m, out};
+    return launch_map(fn, n, aligned16(m, out, out), S(stream), "mask_not");
+}
+
+extern "C" ec_status ec_mask_counts_device(const uint8_t* m, size_t n, uint64_t* counts2_dev, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!counts2_dev || (n > 0 && !m)) return set_error(EC_ERR_ARG, "ec_mask_counts_device: null pointer");
+    Scratch sc;
+    ec_status st = get_scratch(S(stream), &sc);
+    if (st != EC_OK) return st;
+    unsigned grid = 0;
+    if (n > 0) {
+        int cap = g_cus * g_tuning.reduce_bpc;
+        if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
+        const bool al = (reinterpret_cast<uintptr_t>(m) & 15u) == 0;
+        size_t tiles = al ? (n / 16 + size_t(kBlock) * kReduceU - 1) / (size_t(kBlock) * kReduceU) : (n + kBlock - 1) / kBlock;
+        if (tiles < 1) tiles = 1;
+        grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
+        k_mask_count_partials<kReduceU><<<grid, kBlock, 0, S(stream)>>>(m, n, reinterpret_cast<uint64_t*>(sc.dev), al);
+        st = check_launch("mask_counts(partials)");
+        if (st != EC_OK) return st;
+    }
+    k_mask_count_finalize<<<1, kBlock, 0, S(stream)>>>(reinterpret_cast<const uint64_t*>(sc.dev), static_cast<int>(grid), n, counts2_dev);
+    return check_launch("mask_counts(finalize)");
+}
+
+extern "C" ec_status ec_mask_counts(const uint8_t* m, size_t n, uint64_t* n_true, uint64_t* n_false, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!n_true || !n_false) return set_error(EC_ERR_ARG, "ec_mask_counts: null pointer");
+    Scratch sc;
+    ec_status st = get_scratch(S(stream), &sc);
+    if (st != EC_OK) return st;
+    st = ec_mask_counts_device(m, n, reinterpret_cast<uint64_t*>(sc.dev_result()), stream);
+    if (st != EC_OK) return st;
+    st = check_hip(hipMemcpyAsync(sc.host, sc.dev_result(), 2 * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync");
+    if (st != EC_OK) return st;
+    st = check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+    if (st != EC_OK) return st;
+    *n_true = static_cast<uint64_t>(sc.host[0]);
+    *n_false = static_cast<uint64_t>(sc.host[1]);
+    return EC_OK;
+}
+
+// =================================================================== synthetic inputs
+template <typename T>
+static ec_status synth_t(void* dst, size_t n, uint64_t seed, uint64_t base, double lo, double hi, hipStream_t s) {
+    SynthFn<T> fn{static_cast<T*>(dst), seed, base, 1, lo, hi - lo};
+    if constexpr (!is_fp<T>::value) fn.span = static_cast<uint64_t>(hi) - static_cast<uint64_t>(lo) + 1;
+    return launch_map(fn, n, aligned16(dst, dst, dst), s, "synth_fill");
+}
+
+extern "C" ec_status ec_synth_fill(ec_dtype t, void* dst, size_t n, uint64_t seed, uint64_t base, double lo, double hi,
+                                   ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (n == 0) return EC_OK;
+    if (!dst) return set_error(EC_ERR_ARG, "ec_synth_fill: null pointer");
+    switch (t) {
+        case EC_U8: return synth_t<uint8_t>(dst, n, seed, base, lo, hi, S(stream));
+        case EC_U16: return synth_t<uint16_t>(dst, n, seed, base, lo, hi, S(stream));
+        case EC_U32: return synth_t<uint32_t>(dst, n, seed, base, lo, hi, S(stream));
+        case EC_F32: return synth_t<float>(dst, n, seed, base, lo, hi, S(stream));
+        case EC_F64: return synth_t<double>(dst, n, seed, base, lo, hi, S(stream));
+    }
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_synth_fill: dtype %d not supported", int(t));
+}
+
+extern "C" ec_status ec_synth_mask(uint8_t* dst, size_t n, uint64_t seed, uint64_t base, uint32_t pct_nodata, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (n == 0) return EC_OK;
+    if (!dst) return set_error(EC_ERR_ARG, "ec_synth_mask: null pointer");
+    SynthMaskFn fn{dst, seed, base, pct_nodata};
+    return launch_map(fn, n, aligned16(dst, dst, dst), S(stream), "synth_mask");
+}

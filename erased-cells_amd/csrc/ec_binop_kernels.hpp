@@ -1,0 +1,317 @@
+// ec_binop_kernels.hpp — element-wise  out[i] = f64(l[i]) op f64(r[i])  (gfx950).
+//
+// Replaces the iterator chain of src/buffer.rs:327 (+ src/value.rs:199-217 per
+// cell) and its scalar-rhs sibling src/buffer.rs:346-352.
+//
+// Data layout / access plan: the output is always f64, so
+// it is the widest stream (8 of the 11 B/cell for u8÷u16).  Work is cut into
+// chunks of 128 cells = one `global_store_dwordx4` per lane per chunk (1 KiB,
+// fully coalesced).  The narrow operand streams are moved in one of two ways:
+//   DIRECT  lane-contiguous narrow loads: 2 cells per lane per chunk
+//           (ushort / dword / dwordx2 / dwordx4 by operand width).
+//   LDS     the wave loads its whole tile of a ≤2-byte operand with 16-B-per-lane
+//           coalesced loads into a wave-private LDS slab, then each lane reads
+//           back the two cells that belong to its 16-B output slot and widens
+//           them ("LDS staging for the widening step").  The slab is private
+//           to the wave, so no workgroup barrier is needed.
+// A block owns tiles of U chunks per wave; tiles are dealt round-robin to a
+// grid capped at a few blocks per CU (grid-stride).  There is no reuse between
+// blocks (each 128-B line is touched by exactly one wave), so no XCD-aware
+// remap is needed for L2 locality.
+#pragma once
+
+#include "ec_device.hpp"
+
+namespace ecd {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+template <bool NT, typename V>
+__device__ __forceinline__ void store_vec(V* p, V v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+template <bool NT, typename V>
+__device__ __forceinline__ V load_vec(const V* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+// Scalar rhs is modelled as an operand "stream" that costs no loads.
+struct ScalarRhs { double value; };
+
+// ---------------------------------------------------------------------------
+// DIRECT variant. Grid-stride over block tiles of kBlock*U pairs (2 cells each).
+// Requires l, r, out aligned to 2*sizeof(elem) / 16 B; the launcher checks.
+// ---------------------------------------------------------------------------
+template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
+__device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const R* __restrict__ r,
+                                                  double* __restrict__ out, size_t n) {
+    using L2 = vec<L, 2>;
+    using R2 = vec<R, 2>;
+    using D2 = vec<double, 2>;
+    constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    const size_t npairs = n >> 1;
+    constexpr size_t TILE = size_t(kBlock) * U;
+    const size_t ntiles = (npairs + TILE - 1) / TILE;
+    const L2* __restrict__ lp = reinterpret_cast<const L2*>(l);
+    const R2* __restrict__ rp = reinterpret_cast<const R2*>(r);
+    D2* __restrict__ op = reinterpret_cast<D2*>(out);
+
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t base = tile * TILE + threadIdx.x;
+        if (tile * TILE + TILE <= npairs) {
+            L2 a[U];
+            R2 b[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                a[j] = load_vec<NT_LD>(lp + base + size_t(j) * kBlock);
+                b[j] = load_vec<NT_LD>(rp + base + size_t(j) * kBlock);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                D2 o;
+                o.x = cell_op<OP, FP>(to_f64(a[j].x), to_f64(b[j].x));
+                o.y = cell_op<OP, FP>(to_f64(a[j].y), to_f64(b[j].y));
+                store_vec<NT_ST>(op + base + size_t(j) * kBlock, o);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const size_t p = base + size_t(j) * kBlock;
+                if (p < npairs) {
+                    L2 a = lp[p];
+                    R2 b = rp[p];
+                    D2 o;
+                    o.x = cell_op<OP, FP>(to_f64(a.x), to_f64(b.x));
+                    o.y = cell_op<OP, FP>(to_f64(a.y), to_f64(b.y));
+                    op[p] = o;
+                }
+            }
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        out[n - 1] = cell_op<OP, FP>(to_f64(l[n - 1]), to_f64(r[n - 1]));
+}
+
+template <typename L, int OP, int U, bool NT_ST, bool NT_LD>
+__global__ __launch_bounds__(kBlock) void k_binop_scalar_direct(const L* __restrict__ l, double s,
+                                                                double* __restrict__ out, size_t n) {
+    using L2 = vec<L, 2>;
+    using D2 = vec<double, 2>;
+    // the scalar may be any of the 10 types, converted to f64 on the host: treat as FP input
+    constexpr bool FP = true;
+    const size_t npairs = n >> 1;
+    constexpr size_t TILE = size_t(kBlock) * U;
+    const size_t ntiles = (npairs + TILE - 1) / TILE;
+    const L2* __restrict__ lp = reinterpret_cast<const L2*>(l);
+    D2* __restrict__ op = reinterpret_cast<D2*>(out);
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t base = tile * TILE + threadIdx.x;
+        if (tile * TILE + TILE <= npairs) {
+            L2 a[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) a[j] = load_vec<NT_LD>(lp + base + size_t(j) * kBlock);
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                D2 o;
+                o.x = cell_op<OP, FP>(to_f64(a[j].x), s);
+                o.y = cell_op<OP, FP>(to_f64(a[j].y), s);
+                store_vec<NT_ST>(op + base + size_t(j) * kBlock, o);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const size_t p = base + size_t(j) * kBlock;
+                if (p < npairs) {
+                    L2 a = lp[p];
+                    D2 o;
+                    o.x = cell_op<OP, FP>(to_f64(a.x), s);
+                    o.y = cell_op<OP, FP>(to_f64(a.y), s);
+                    op[p] = o;
+                }
+            }
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = cell_op<OP, FP>(to_f64(l[n - 1]), s);
+}
+
+// Any alignment, any n: one cell per lane. Correctness fallback for odd offsets.
+template <typename L, typename R, int OP>
+__global__ __launch_bounds__(kBlock) void k_binop_cellwise(const L* __restrict__ l, const R* __restrict__ r,
+                                                           double* __restrict__ out, size_t n) {
+    constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    const size_t stride = size_t(gridDim.x) * kBlock;
+    for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = cell_op<OP, FP>(to_f64(l[i]), to_f64(r[i]));
+}
+
+template <typename L, int OP>
+__global__ __launch_bounds__(kBlock) void k_binop_scalar_cellwise(const L* __restrict__ l, double s,
+                                                                  double* __restrict__ out, size_t n) {
+    const size_t stride = size_t(gridDim.x) * kBlock;
+    for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = cell_op<OP, true>(to_f64(l[i]), s);
+}
+
+// ---------------------------------------------------------------------------
+// LDS-staged variant.  Wave tile = 128*U cells (U chunks of one dwordx4 store
+// per lane).  Operands of ≤2 bytes are staged through a wave-private LDS slab
+// with 16-B-per-lane loads; wider operands already load ≥8 B per lane and go
+// direct.  U*sizeof(T) must be a multiple of 8 so the slab is whole 1-KiB rows.
+// ---------------------------------------------------------------------------
+template <typename T, int U>
+struct Staged {
+    static constexpr bool value = sizeof(T) <= 2;
+    static constexpr int kBytes = 128 * U * int(sizeof(T));  // per wave tile
+    static constexpr int kRows = kBytes / 1024;              // 16-B loads per lane
+    static_assert(!value || (kBytes % 1024 == 0), "U*sizeof(T) must be a multiple of 8");
+};
+
+using u32x4 = vec<uint32_t, 4>;
+
+template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
+__device__ __forceinline__ void binop_lds_body(const L* __restrict__ l, const R* __restrict__ r,
+                                               double* __restrict__ out, size_t n) {
+    using L2 = vec<L, 2>;
+    using R2 = vec<R, 2>;
+    using D2 = vec<double, 2>;
+    constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    constexpr bool SL = Staged<L, U>::value, SR = Staged<R, U>::value;
+    constexpr int LB = SL ? Staged<L, U>::kBytes : 16, RB = SR ? Staged<R, U>::kBytes : 16;
+    constexpr size_t WTILE = 128 * size_t(U);  // cells per wave tile
+
+    __shared__ __attribute__((aligned(16))) unsigned char slab_l[kWavesPerBlock][LB];
+    __shared__ __attribute__((aligned(16))) unsigned char slab_r[kWavesPerBlock][RB];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const size_t nfull = n / WTILE;  // whole wave tiles
+    const size_t gwaves = size_t(gridDim.x) * kWavesPerBlock;
+
+    // tiles are dealt block-major so a block's four waves stream 4 adjacent tiles
+    for (size_t t = size_t(blockIdx.x) * kWavesPerBlock + wave; t < nfull; t += gwaves) {
+        const size_t cell0 = t * WTILE;
+        u32x4 sl[SL ? Staged<L, U>::kRows : 1];
+        u32x4 sr[SR ? Staged<R, U>::kRows : 1];
+        L2 a[U];
+        R2 b[U];
+        if constexpr (SL) {
+            const u32x4* g = reinterpret_cast<const u32x4*>(l + cell0);
+#pragma unroll
+            for (int k = 0; k < Staged<L, U>::kRows; ++k) sl[k] = load_vec<NT_LD>(g + k * kWave + lane);
+        } else {
+            const L2* g = reinterpret_cast<const L2*>(l + cell0);
+#pragma unroll
+            for (int j = 0; j < U; ++j) a[j] = load_vec<NT_LD>(g + j * kWave + lane);
+        }
+        if constexpr (SR) {
+            const u32x4* g = reinterpret_cast<const u32x4*>(r + cell0);
+#pragma unroll
+            for (int k = 0; k < Staged<R, U>::kRows; ++k) sr[k] = load_vec<NT_LD>(g + k * kWave + lane);
+        } else {
+            const R2* g = reinterpret_cast<const R2*>(r + cell0);
+#pragma unroll
+            for (int j = 0; j < U; ++j) b[j] = load_vec<NT_LD>(g + j * kWave + lane);
+        }
+        if constexpr (SL) {
+            u32x4* s = reinterpret_cast<u32x4*>(slab_l[wave]);
+#pragma unroll
+            for (int k = 0; k < Staged<L, U>::kRows; ++k) s[k * kWave + lane] = sl[k];
+        }
+        if constexpr (SR) {
+            u32x4* s = reinterpret_cast<u32x4*>(slab_r[wave]);
+#pragma unroll
+            for (int k = 0; k < Staged<R, U>::kRows; ++k) s[k * kWave + lane] = sr[k];
+        }
+        if constexpr (SL || SR) {
+            // the slab is private to this wave: order the wave's own LDS writes before its reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if constexpr (SL) {
+            const L2* s = reinterpret_cast<const L2*>(slab_l[wave]);
+#pragma unroll
+            for (int j = 0; j < U; ++j) a[j] = s[j * kWave + lane];
+        }
+        if constexpr (SR) {
+            const R2* s = reinterpret_cast<const R2*>(slab_r[wave]);
+#pragma unroll
+            for (int j = 0; j < U; ++j) b[j] = s[j * kWave + lane];
+        }
+        D2* o2 = reinterpret_cast<D2*>(out + cell0);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            D2 o;
+            o.x = cell_op<OP, FP>(to_f64(a[j].x), to_f64(b[j].x));
+            o.y = cell_op<OP, FP>(to_f64(a[j].y), to_f64(b[j].y));
+            store_vec<NT_ST>(o2 + j * kWave + lane, o);
+        }
+        if constexpr (SL || SR) {
+            // next iteration overwrites the slab: keep this iteration's reads ahead of those writes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ragged tail (< one wave tile): cell-wise by the whole grid
+    const size_t tail0 = nfull * WTILE;
+    const size_t stride = size_t(gridDim.x) * kBlock;
+    for (size_t i = tail0 + size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = cell_op<OP, FP>(to_f64(l[i]), to_f64(r[i]));
+}
+
+template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
+__global__ __launch_bounds__(kBlock) void k_binop_direct(const L* __restrict__ l, const R* __restrict__ r,
+                                                         double* __restrict__ out, size_t n) {
+    binop_direct_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
+}
+
+template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
+__global__ __launch_bounds__(kBlock) void k_binop_lds(const L* __restrict__ l, const R* __restrict__ r,
+                                                      double* __restrict__ out, size_t n) {
+    binop_lds_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
+}
+
+// `&Mask & &Mask` (src/masked/mask.rs:129-140) as a block-tiled 16-B-per-lane stream.
+__device__ __forceinline__ void mask_and_body(const uint8_t* __restrict__ lm, const uint8_t* __restrict__ rm,
+                                              uint8_t* __restrict__ om, size_t n) {
+    const size_t ngroups = n / 16;
+    const u32x4* __restrict__ a = reinterpret_cast<const u32x4*>(lm);
+    const u32x4* __restrict__ b = reinterpret_cast<const u32x4*>(rm);
+    u32x4* __restrict__ o = reinterpret_cast<u32x4*>(om);
+    const size_t stride = size_t(gridDim.x) * kBlock;
+    for (size_t g = size_t(blockIdx.x) * kBlock + threadIdx.x; g < ngroups; g += stride) o[g] = a[g] & b[g];
+    if (blockIdx.x == 0)
+        for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) om[i] = lm[i] & rm[i];
+}
+
+// impl $trt for &MaskedCellBuffer (src/masked/masked_buffer.rs:326-335) in one
+// launch: the buffer op over ALL cells (masked-out cells are still computed,
+// :331) and the mask AND (:333), each with its own lane->cell mapping so both
+// streams stay 16 B per lane.
+template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD, bool LDS>
+__global__ __launch_bounds__(kBlock) void k_masked_binop(const L* __restrict__ l, const uint8_t* __restrict__ lm,
+                                                         const R* __restrict__ r, const uint8_t* __restrict__ rm,
+                                                         double* __restrict__ out, uint8_t* __restrict__ om, size_t n) {
+    if constexpr (LDS) binop_lds_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
+    else binop_direct_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
+    mask_and_body(lm, rm, om, n);
+}
+
+template <typename L, typename R, int OP>
+__global__ __launch_bounds__(kBlock) void k_masked_binop_cellwise(const L* __restrict__ l, const uint8_t* __restrict__ lm,
+                                                                  const R* __restrict__ r, const uint8_t* __restrict__ rm,
+                                                                  double* __restrict__ out, uint8_t* __restrict__ om, size_t n) {
+    constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    const size_t stride = size_t(gridDim.x) * kBlock;
+    for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        out[i] = cell_op<OP, FP>(to_f64(l[i]), to_f64(r[i]));
+        om[i] = lm[i] & rm[i];
+    }
+}
+
+}  // namespace ecd

@@ -1,0 +1,134 @@
+// ec_binop_tu.hpp — launchers for one arithmetic op over all 100 operand-type
+// pairs (the `with_ct!` × `with_ct!` product the reference test
+// src/buffer.rs:595-614 walks).  Each of ec_binop_{add,sub,mul,div}.hip includes
+// this with EC_TU_OP set, so the four ops compile in parallel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ec_binop_kernels.hpp"
+#include "ec_runtime.hpp"
+
+namespace ecd {
+
+template <typename L, typename R, int OP>
+static ec_status launch_binop_pair(const void* l, const void* r, size_t n, double* out, hipStream_t s) {
+    const Tuning& tu = tuning();
+    const L* lp = static_cast<const L*>(l);
+    const R* rp = static_cast<const R*>(r);
+    constexpr int U = kBinopU;
+    if (!aligned16(l, r, out)) {
+        k_binop_cellwise<L, R, OP><<<grid_for((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, rp, out, n);
+        return check_launch("binop(cellwise)");
+    }
+    constexpr bool kCanStage = Staged<L, U>::value || Staged<R, U>::value;
+    if (kCanStage && tu.binop_variant == 1) {
+        const size_t tiles = (n / (128 * size_t(U)) + kWavesPerBlock - 1) / kWavesPerBlock;
+        k_binop_lds<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, rp, out, n);
+        return check_launch("binop(lds)");
+    }
+    const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
+    k_binop_direct<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, rp, out, n);
+    return check_launch("binop(direct)");
+}
+
+template <typename L, typename R, int OP>
+static ec_status launch_masked_pair(const void* l, const uint8_t* lm, const void* r, const uint8_t* rm, size_t n,
+                                    double* out, uint8_t* om, hipStream_t s) {
+    const Tuning& tu = tuning();
+    const L* lp = static_cast<const L*>(l);
+    const R* rp = static_cast<const R*>(r);
+    constexpr int U = kBinopU;
+    if (!aligned16(l, r, out) || !aligned16(lm, rm, om)) {
+        k_masked_binop_cellwise<L, R, OP><<<grid_for((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
+        return check_launch("masked_binop(cellwise)");
+    }
+    constexpr bool kCanStage = Staged<L, U>::value || Staged<R, U>::value;
+    if (kCanStage && tu.binop_variant == 1) {
+        const size_t tiles = (n / (128 * size_t(U)) + kWavesPerBlock - 1) / kWavesPerBlock;
+        k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, true><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
+        return check_launch("masked_binop(lds)");
+    }
+    const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
+    k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, false><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
+    return check_launch("masked_binop(direct)");
+}
+
+template <typename L, int OP>
+static ec_status launch_scalar(const void* l, double rhs, size_t n, double* out, hipStream_t s) {
+    const Tuning& tu = tuning();
+    const L* lp = static_cast<const L*>(l);
+    constexpr int U = kBinopU;
+    if (!aligned16(l, out, out)) {
+        k_binop_scalar_cellwise<L, OP><<<grid_for((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, rhs, out, n);
+        return check_launch("binop_scalar(cellwise)");
+    }
+    const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
+    k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, rhs, out, n);
+    return check_launch("binop_scalar(direct)");
+}
+
+// Type-erased dispatch: the 10-way × 10-way match `with_ct!` stamps in the reference.
+template <int OP>
+ec_status dispatch_binop(int lt, const void* l, int rt, const void* r, size_t n, double* out, hipStream_t s) {
+#define EC_ROW(LID, LT)                                                                         \
+    case LID:                                                                                   \
+        switch (rt) {                                                                           \
+            case EC_U8: return launch_binop_pair<LT, uint8_t, OP>(l, r, n, out, s);             \
+            case EC_U16: return launch_binop_pair<LT, uint16_t, OP>(l, r, n, out, s);           \
+            case EC_U32: return launch_binop_pair<LT, uint32_t, OP>(l, r, n, out, s);           \
+            case EC_U64: return launch_binop_pair<LT, uint64_t, OP>(l, r, n, out, s);           \
+            case EC_I8: return launch_binop_pair<LT, int8_t, OP>(l, r, n, out, s);              \
+            case EC_I16: return launch_binop_pair<LT, int16_t, OP>(l, r, n, out, s);            \
+            case EC_I32: return launch_binop_pair<LT, int32_t, OP>(l, r, n, out, s);            \
+            case EC_I64: return launch_binop_pair<LT, int64_t, OP>(l, r, n, out, s);            \
+            case EC_F32: return launch_binop_pair<LT, float, OP>(l, r, n, out, s);              \
+            case EC_F64: return launch_binop_pair<LT, double, OP>(l, r, n, out, s);             \
+        }                                                                                       \
+        break;
+    switch (lt) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "binop: bad dtype");
+}
+
+template <int OP>
+ec_status dispatch_masked_binop(int lt, const void* l, const uint8_t* lm, int rt, const void* r, const uint8_t* rm,
+                                size_t n, double* out, uint8_t* om, hipStream_t s) {
+#define EC_ROW(LID, LT)                                                                                   \
+    case LID:                                                                                             \
+        switch (rt) {                                                                                     \
+            case EC_U8: return launch_masked_pair<LT, uint8_t, OP>(l, lm, r, rm, n, out, om, s);          \
+            case EC_U16: return launch_masked_pair<LT, uint16_t, OP>(l, lm, r, rm, n, out, om, s);        \
+            case EC_U32: return launch_masked_pair<LT, uint32_t, OP>(l, lm, r, rm, n, out, om, s);        \
+            case EC_U64: return launch_masked_pair<LT, uint64_t, OP>(l, lm, r, rm, n, out, om, s);        \
+            case EC_I8: return launch_masked_pair<LT, int8_t, OP>(l, lm, r, rm, n, out, om, s);           \
+            case EC_I16: return launch_masked_pair<LT, int16_t, OP>(l, lm, r, rm, n, out, om, s);         \
+            case EC_I32: return launch_masked_pair<LT, int32_t, OP>(l, lm, r, rm, n, out, om, s);         \
+            case EC_I64: return launch_masked_pair<LT, int64_t, OP>(l, lm, r, rm, n, out, om, s);         \
+            case EC_F32: return launch_masked_pair<LT, float, OP>(l, lm, r, rm, n, out, om, s);           \
+            case EC_F64: return launch_masked_pair<LT, double, OP>(l, lm, r, rm, n, out, om, s);          \
+        }                                                                                                 \
+        break;
+    switch (lt) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "masked_binop: bad dtype");
+}
+
+template <int OP>
+ec_status dispatch_binop_scalar(int lt, const void* l, double rhs, size_t n, double* out, hipStream_t s) {
+#define EC_ROW(LID, LT) case LID: return launch_scalar<LT, OP>(l, rhs, n, out, s);
+    switch (lt) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return set_error(EC_ERR_UNSUPPORTED_TYPE, "binop_scalar: bad dtype");
+}
+
+}  // namespace ecd
+
+#ifdef EC_TU_OP
+namespace ecd {
+template ec_status dispatch_binop<EC_TU_OP>(int, const void*, int, const void*, size_t, double*, hipStream_t);
+template ec_status dispatch_masked_binop<EC_TU_OP>(int, const void*, const uint8_t*, int, const void*, const uint8_t*,
+                                                   size_t, double*, uint8_t*, hipStream_t);
+template ec_status dispatch_binop_scalar<EC_TU_OP>(int, const void*, double, size_t, double*, hipStream_t);
+}  // namespace ecd
+#endif

@@ -1,0 +1,118 @@
+// ec_device.hpp — per-cell device functions shared by every kernel (gfx950).
+//
+// The scalar semantics come from src/value.rs of the reference:
+//   binop   value.rs:199-217  (l as f64) op (r as f64), always Float64
+//   neg     value.rs:224-240
+//   order   value.rs:248-265  ints natural, floats total_cmp
+// NaN policy: results match what the reference produces on x86-64
+// (its CI platform): an operand NaN propagates lhs-first and quieted, a
+// generated NaN is the x86 default 0xFFF8000000000000.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "erased_cells.h"
+
+namespace ecd {
+
+template <typename T, int N>
+using vec = T __attribute__((ext_vector_type(N)));
+
+// with_ct! (src/lib.rs:85-101): X(dtype code, C type)
+#define EC_WITH_CT(X)      \
+    X(EC_U8, uint8_t)      \
+    X(EC_U16, uint16_t)    \
+    X(EC_U32, uint32_t)    \
+    X(EC_U64, uint64_t)    \
+    X(EC_I8, int8_t)       \
+    X(EC_I16, int16_t)     \
+    X(EC_I32, int32_t)     \
+    X(EC_I64, int64_t)     \
+    X(EC_F32, float)       \
+    X(EC_F64, double)
+
+template <typename T> struct is_fp { static constexpr bool value = false; };
+template <> struct is_fp<float> { static constexpr bool value = true; };
+template <> struct is_fp<double> { static constexpr bool value = true; };
+
+constexpr uint64_t kNegQNaN = 0xFFF8000000000000ull;  // x86-64 SSE default NaN
+constexpr uint64_t kQuietBit = 0x0008000000000000ull;
+
+__device__ __forceinline__ uint64_t f64_bits(double d) { return __builtin_bit_cast(uint64_t, d); }
+__device__ __forceinline__ double bits_f64(uint64_t b) { return __builtin_bit_cast(double, b); }
+
+// Rust `as f64`: ints round to nearest even, f32 widens exactly.
+template <typename T>
+__device__ __forceinline__ double to_f64(T v) { return static_cast<double>(v); }
+
+template <int OP>
+__device__ __forceinline__ double apply_op(double a, double b) {
+    if constexpr (OP == EC_ADD) return a + b;
+    else if constexpr (OP == EC_SUB) return a - b;
+    else if constexpr (OP == EC_MUL) return a * b;
+    else return a / b;  // IEEE-correct v_div_scale/v_rcp/fma/v_div_fmas/v_div_fixup sequence
+}
+
+// One cell of cv_bin_op!.  FP_IN: either operand type is floating point (an
+// operand can then be NaN/inf); with integer operands only 0/0 can make a NaN.
+template <int OP, bool FP_IN>
+__device__ __forceinline__ double cell_op(double a, double b) {
+    double res = apply_op<OP>(a, b);
+    if constexpr (FP_IN) {
+        if (__builtin_expect(res != res, 0)) {
+            uint64_t ba = f64_bits(a), bb = f64_bits(b);
+            uint64_t fix = (a != a) ? (ba | kQuietBit) : (b != b) ? (bb | kQuietBit) : kNegQNaN;
+            res = bits_f64(fix);
+        }
+    } else if constexpr (OP == EC_DIV) {
+        // branch-free: a select keeps the unrolled cells' divide chains interleavable
+        res = (res != res) ? bits_f64(kNegQNaN) : res;
+    }
+    return res;
+}
+
+// f32/f64::total_cmp keys (src/value.rs:260-261) and their integer siblings:
+// every cell type maps to an int64 whose natural order is the reference order.
+template <typename T>
+__device__ __host__ __forceinline__ int64_t order_key(T v) {
+    if constexpr (sizeof(T) == 8 && !is_fp<T>::value && T(-1) > T(0)) {
+        return static_cast<int64_t>(static_cast<uint64_t>(v) ^ 0x8000000000000000ull);  // u64
+    } else if constexpr (!is_fp<T>::value) {
+        return static_cast<int64_t>(v);
+    } else if constexpr (sizeof(T) == 4) {
+        int32_t b = __builtin_bit_cast(int32_t, v);
+        b ^= static_cast<int32_t>(static_cast<uint32_t>(b >> 31) >> 1);
+        return b;
+    } else {
+        int64_t b = __builtin_bit_cast(int64_t, v);
+        b ^= static_cast<int64_t>(static_cast<uint64_t>(b >> 63) >> 1);
+        return b;
+    }
+}
+
+template <typename T>
+__device__ __host__ __forceinline__ T key_value(int64_t k) {
+    if constexpr (sizeof(T) == 8 && !is_fp<T>::value && T(-1) > T(0)) {
+        return static_cast<T>(static_cast<uint64_t>(k) ^ 0x8000000000000000ull);
+    } else if constexpr (!is_fp<T>::value) {
+        return static_cast<T>(k);
+    } else if constexpr (sizeof(T) == 4) {
+        int32_t b = static_cast<int32_t>(k);
+        b ^= static_cast<int32_t>(static_cast<uint32_t>(b >> 31) >> 1);
+        return __builtin_bit_cast(float, b);
+    } else {
+        int64_t b = k;
+        b ^= static_cast<int64_t>(static_cast<uint64_t>(b >> 63) >> 1);
+        return __builtin_bit_cast(double, b);
+    }
+}
+
+__device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+}  // namespace ecd

@@ -1,0 +1,253 @@
+// ec_map_kernels.hpp — the one-pass, per-cell kernels other than the binary
+// arithmetic: neg, convert, fill, mask build/select/and/or/not (gfx950).
+//
+// All of them are pure streaming maps with different cell widths on the two
+// sides.  One skeleton serves them: the widest stream moves 16 B per lane per
+// access (CPL = 16 / widest cell cells per lane); the narrower streams then move
+// CPL*width bytes per lane, still lane-contiguous, so every wave instruction
+// touches one contiguous span.  A block tile is U such groups per lane, loads
+// first, then compute + stores; tiles are dealt round-robin to a grid capped at
+// a few blocks per CU.  Ragged tails and unaligned pointers take the cell-wise
+// kernel (correct for any alignment, one cell per lane).
+#pragma once
+
+#include "ec_binop_kernels.hpp"
+
+namespace ecd {
+
+// Fn interface:
+//   static constexpr int CPL;            cells per lane-group
+//   typename In;                         what load() returns
+//   In   load(size_t g) const;           loads for group g (cells [g*CPL, g*CPL+CPL))
+//   void store(size_t g, const In&) const;  compute + store for group g
+//   void cell(size_t i) const;           one cell, any alignment
+template <typename Fn, int U>
+__global__ __launch_bounds__(kBlock) void k_map(Fn fn, size_t n) {
+    using In = typename Fn::In;
+    constexpr size_t CPL = Fn::CPL;
+    const size_t ngroups = n / CPL;
+    constexpr size_t TILE = size_t(kBlock) * U;
+    const size_t ntiles = (ngroups + TILE - 1) / TILE;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t base = tile * TILE + threadIdx.x;
+        if (tile * TILE + TILE <= ngroups) {
+            In x[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) x[j] = fn.load(base + size_t(j) * kBlock);
+#pragma unroll
+            for (int j = 0; j < U; ++j) fn.store(base + size_t(j) * kBlock, x[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const size_t g = base + size_t(j) * kBlock;
+                if (g < ngroups) fn.store(g, fn.load(g));
+            }
+        }
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kBlock) fn.cell(i);
+}
+
+template <typename Fn>
+__global__ __launch_bounds__(kBlock) void k_map_cellwise(Fn fn, size_t n) {
+    const size_t stride = size_t(gridDim.x) * kBlock;
+    for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) fn.cell(i);
+}
+
+template <int A, int B>
+struct max_of { static constexpr int value = A > B ? A : B; };
+
+// ---- convert: BufferOps::convert (src/buffer.rs:161-164), per cell
+// CellValue::convert (src/value.rs:74-98) == Rust `as` for every legal pair.
+template <typename S, typename D>
+struct ConvertFn {
+    static constexpr int CPL = 16 / max_of<sizeof(S), sizeof(D)>::value;
+    using SV = vec<S, CPL>;
+    using DV = vec<D, CPL>;
+    using In = SV;
+    const S* __restrict__ src;
+    D* __restrict__ dst;
+    __device__ __forceinline__ In load(size_t g) const { return reinterpret_cast<const SV*>(src)[g]; }
+    __device__ __forceinline__ void store(size_t g, const In& x) const {
+        reinterpret_cast<DV*>(dst)[g] = __builtin_convertvector(x, DV);
+    }
+    __device__ __forceinline__ void cell(size_t i) const { dst[i] = static_cast<D>(src[i]); }
+};
+
+// ---- neg: impl Neg for CellValue (src/value.rs:224-240)
+template <typename T> struct NegOut { using type = T; };
+template <> struct NegOut<uint8_t> { using type = int16_t; };
+template <> struct NegOut<uint16_t> { using type = int32_t; };
+template <> struct NegOut<uint32_t> { using type = double; };
+template <> struct NegOut<uint64_t> { using type = double; };
+
+template <typename T>
+__device__ __forceinline__ typename NegOut<T>::type neg_cell(T v) {
+    using O = typename NegOut<T>::type;
+    if constexpr (is_fp<T>::value) {
+        return -v;  // sign-bit flip, NaN included
+    } else if constexpr (is_fp<O>::value) {
+        return -static_cast<double>(v);  // u32/u64: -(v as f64)
+    } else if constexpr (sizeof(O) > sizeof(T)) {
+        return static_cast<O>(-static_cast<O>(v));  // u8 -> i16, u16 -> i32
+    } else {
+        using UT = typename NegOut<T>::type;  // signed: wrap at MIN like a release build
+        if constexpr (sizeof(T) == 8) return static_cast<UT>(0ull - static_cast<uint64_t>(v));
+        else return static_cast<UT>(0u - static_cast<uint32_t>(v));
+    }
+}
+
+template <typename T>
+struct NegFn {
+    using O = typename NegOut<T>::type;
+    static constexpr int CPL = 16 / max_of<sizeof(T), sizeof(O)>::value;
+    using SV = vec<T, CPL>;
+    using DV = vec<O, CPL>;
+    using In = SV;
+    const T* __restrict__ src;
+    O* __restrict__ dst;
+    __device__ __forceinline__ In load(size_t g) const { return reinterpret_cast<const SV*>(src)[g]; }
+    __device__ __forceinline__ void store(size_t g, const In& x) const {
+        DV o;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) o[k] = neg_cell<T>(x[k]);
+        reinterpret_cast<DV*>(dst)[g] = o;
+    }
+    __device__ __forceinline__ void cell(size_t i) const { dst[i] = neg_cell<T>(src[i]); }
+};
+
+// ---- fill: BufferOps::fill (src/buffer.rs:79-88). W = cell width in bytes.
+template <typename W>
+struct FillFn {
+    static constexpr int CPL = 16 / sizeof(W);
+    using DV = vec<W, CPL>;
+    struct In {};
+    W* __restrict__ dst;
+    W value;
+    __device__ __forceinline__ In load(size_t) const { return In{}; }
+    __device__ __forceinline__ void store(size_t g, const In&) const {
+        DV o;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) o[k] = value;
+        reinterpret_cast<DV*>(dst)[g] = o;
+    }
+    __device__ __forceinline__ void cell(size_t i) const { dst[i] = value; }
+};
+
+// ---- mask_from_nodata: from_vec_with_nodata (src/masked/masked_buffer.rs:62-71);
+// equality under the total order is bit equality (src/masked/nodata.rs:42-49 ->
+// src/value.rs:248-271). W = unsigned type of the cell width.
+template <typename W>
+struct MaskFromNodataFn {
+    static constexpr int CPL = 16 / sizeof(W);
+    using SV = vec<W, CPL>;
+    using MV = vec<uint8_t, CPL>;
+    using In = SV;
+    const W* __restrict__ src;
+    uint8_t* __restrict__ mask;
+    W nd;
+    __device__ __forceinline__ In load(size_t g) const { return reinterpret_cast<const SV*>(src)[g]; }
+    __device__ __forceinline__ void store(size_t g, const In& x) const {
+        MV m;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) m[k] = x[k] != nd;
+        reinterpret_cast<MV*>(mask)[g] = m;
+    }
+    __device__ __forceinline__ void cell(size_t i) const { mask[i] = src[i] != nd; }
+};
+
+// ---- mask_select: to_vec_with_nodata (src/masked/masked_buffer.rs:143-148)
+template <typename W>
+struct MaskSelectFn {
+    static constexpr int CPL = 16 / sizeof(W);
+    using SV = vec<W, CPL>;
+    using MV = vec<uint8_t, CPL>;
+    struct In { SV x; MV m; };
+    const W* __restrict__ src;
+    const uint8_t* __restrict__ mask;
+    W* __restrict__ dst;
+    W nd;
+    __device__ __forceinline__ In load(size_t g) const {
+        return In{reinterpret_cast<const SV*>(src)[g], reinterpret_cast<const MV*>(mask)[g]};
+    }
+    __device__ __forceinline__ void store(size_t g, const In& in) const {
+        SV o;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) o[k] = in.m[k] ? in.x[k] : nd;
+        reinterpret_cast<SV*>(dst)[g] = o;
+    }
+    __device__ __forceinline__ void cell(size_t i) const { dst[i] = mask[i] ? src[i] : nd; }
+};
+
+// ---- Mask BitAnd / BitOr / Not (src/masked/mask.rs:103-163): bytes are 0/1.
+template <int KIND>  // 0 and, 1 or
+struct MaskBin {
+    static constexpr int CPL = 16;
+    struct In { u32x4 a, b; };
+    const uint8_t* __restrict__ l;
+    const uint8_t* __restrict__ r;
+    uint8_t* __restrict__ out;
+    __device__ __forceinline__ In load(size_t g) const {
+        return In{reinterpret_cast<const u32x4*>(l)[g], reinterpret_cast<const u32x4*>(r)[g]};
+    }
+    __device__ __forceinline__ void store(size_t g, const In& in) const {
+        reinterpret_cast<u32x4*>(out)[g] = KIND == 0 ? (in.a & in.b) : (in.a | in.b);
+    }
+    __device__ __forceinline__ void cell(size_t i) const { out[i] = KIND == 0 ? (l[i] & r[i]) : (l[i] | r[i]); }
+};
+
+struct MaskNot {
+    static constexpr int CPL = 16;
+    using In = u32x4;
+    const uint8_t* __restrict__ m;
+    uint8_t* __restrict__ out;
+    __device__ __forceinline__ In load(size_t g) const { return reinterpret_cast<const u32x4*>(m)[g]; }
+    __device__ __forceinline__ void store(size_t g, const In& x) const {
+        reinterpret_cast<u32x4*>(out)[g] = x ^ 0x01010101u;
+    }
+    __device__ __forceinline__ void cell(size_t i) const { out[i] = m[i] ^ 1; }
+};
+
+// ---- synthetic inputs for bench/tests: counter-based, no stored vectors.
+template <typename T>
+struct SynthFn {
+    static constexpr int CPL = 16 / sizeof(T);
+    using DV = vec<T, CPL>;
+    struct In {};
+    T* __restrict__ dst;
+    uint64_t seed, base, span;
+    double lo, width;
+    __device__ __forceinline__ T gen(size_t i) const {
+        uint64_t h = splitmix64(seed ^ (base + i));
+        if constexpr (is_fp<T>::value) return static_cast<T>(lo + width * (double(h >> 11) * 0x1.0p-53));
+        else return static_cast<T>(uint64_t(lo) + h % span);
+    }
+    __device__ __forceinline__ In load(size_t) const { return In{}; }
+    __device__ __forceinline__ void store(size_t g, const In&) const {
+        DV o;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) o[k] = gen(g * CPL + k);
+        reinterpret_cast<DV*>(dst)[g] = o;
+    }
+    __device__ __forceinline__ void cell(size_t i) const { dst[i] = gen(i); }
+};
+
+struct SynthMaskFn {
+    static constexpr int CPL = 16;
+    using DV = vec<uint8_t, 16>;
+    struct In {};
+    uint8_t* __restrict__ dst;
+    uint64_t seed, base;
+    uint32_t pct;
+    __device__ __forceinline__ uint8_t gen(size_t i) const { return splitmix64(seed ^ (base + i)) % 100 >= pct; }
+    __device__ __forceinline__ In load(size_t) const { return In{}; }
+    __device__ __forceinline__ void store(size_t g, const In&) const {
+        DV o;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[k] = gen(g * 16 + k);
+        reinterpret_cast<DV*>(dst)[g] = o;
+    }
+    __device__ __forceinline__ void cell(size_t i) const { dst[i] = gen(i); }
+};
+
+}  // namespace ecd

@@ -1,0 +1,281 @@
+// ec_reduce_kernels.hpp — min/max and mask counts (gfx950).
+//
+//   min_max  BufferOps::min_max, src/buffer.rs:169-173 (masked:
+//            src/masked/masked_buffer.rs:208-217), order src/value.rs:248-265,
+//            sentinels (T::MAX, T::MIN) src/ctype.rs:158-179 — finite for floats.
+//   counts   Mask::counts, src/masked/mask.rs:72-80.
+//
+// Plan: read-only stream at 16 B per lane, U loads in flight per lane; each lane
+// folds into register accumulators (packed 16-bit min/max for u16/i16), then a
+// wavefront shuffle-reduce (DPP/ds_bpermute via __shfl_xor, 6 steps), then the
+// four waves of the block combine through 64 B of LDS and lane 0 writes the
+// block's partial.  A one-block finalize kernel folds the partials (≤ 8 per CU)
+// and writes the two order-preserving int64 keys {~key(min), key(max)} — the
+// form a MAX all-reduce over shards needs.  No atomics, so the result is
+// deterministic and needs no zero-initialised memory.
+#pragma once
+
+#include "ec_binop_kernels.hpp"
+
+namespace ecd {
+
+template <typename T> struct Limits;
+#define EC_LIM(T, LO, HI) \
+    template <> struct Limits<T> { static constexpr T lo = LO; static constexpr T hi = HI; };
+EC_LIM(uint8_t, 0, UINT8_MAX)
+EC_LIM(uint16_t, 0, UINT16_MAX)
+EC_LIM(uint32_t, 0, UINT32_MAX)
+EC_LIM(uint64_t, 0, UINT64_MAX)
+EC_LIM(int8_t, INT8_MIN, INT8_MAX)
+EC_LIM(int16_t, INT16_MIN, INT16_MAX)
+EC_LIM(int32_t, INT32_MIN, INT32_MAX)
+EC_LIM(int64_t, INT64_MIN, INT64_MAX)
+EC_LIM(float, -3.402823466e+38f, 3.402823466e+38f)
+EC_LIM(double, -1.7976931348623157e+308, 1.7976931348623157e+308)
+#undef EC_LIM
+
+// The type the per-lane accumulators live in: integers as themselves, floats as
+// their total_cmp keys (same width, signed), so min/max are plain integer ops.
+template <typename T> struct AccT { using type = T; };
+template <> struct AccT<float> { using type = int32_t; };
+template <> struct AccT<double> { using type = int64_t; };
+
+template <typename T>
+__device__ __forceinline__ typename AccT<T>::type acc_key(T v) {
+    if constexpr (is_fp<T>::value) return static_cast<typename AccT<T>::type>(order_key<T>(v));
+    else return v;
+}
+
+template <typename A>
+__device__ __forceinline__ int64_t acc_to_i64(A a) {
+    if constexpr (sizeof(A) == 8 && A(-1) > A(0)) return static_cast<int64_t>(static_cast<uint64_t>(a) ^ 0x8000000000000000ull);
+    else return static_cast<int64_t>(a);
+}
+
+__device__ __forceinline__ int64_t wave_min_i64(int64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int64_t o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int64_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// partials[2*b] = min key, partials[2*b+1] = max key of block b (int64 order keys).
+template <typename T, bool MASKED, int U>
+__global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict__ p, const uint8_t* __restrict__ mask,
+                                                             size_t n, int64_t* __restrict__ partials) {
+    using A = typename AccT<T>::type;
+    constexpr int CPL = 16 / sizeof(T);
+    using TV = vec<T, CPL>;
+    using AV = vec<A, CPL>;
+    using MV = vec<uint8_t, CPL>;
+    const A hi0 = acc_key<T>(Limits<T>::hi), lo0 = acc_key<T>(Limits<T>::lo);
+    AV vmin, vmax;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) { vmin[k] = hi0; vmax[k] = lo0; }
+
+    const size_t ngroups = n / CPL;
+    constexpr size_t TILE = size_t(kBlock) * U;
+    const size_t ntiles = (ngroups + TILE - 1) / TILE;
+    const TV* __restrict__ pv = reinterpret_cast<const TV*>(p);
+    const MV* __restrict__ mv = reinterpret_cast<const MV*>(mask);
+
+    auto fold = [&](const TV& x, const MV& m) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            A key = acc_key<T>(x[k]);
+            A kmin = key, kmax = key;
+            if constexpr (MASKED) {
+                kmin = m[k] ? key : hi0;
+                kmax = m[k] ? key : lo0;
+            }
+            vmin[k] = kmin < vmin[k] ? kmin : vmin[k];
+            vmax[k] = kmax > vmax[k] ? kmax : vmax[k];
+        }
+    };
+
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t base = tile * TILE + threadIdx.x;
+        if (tile * TILE + TILE <= ngroups) {
+            TV x[U];
+            MV m[U] = {};
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                x[j] = __builtin_nontemporal_load(pv + base + size_t(j) * kBlock);
+                if constexpr (MASKED) m[j] = __builtin_nontemporal_load(mv + base + size_t(j) * kBlock);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) fold(x[j], m[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const size_t g = base + size_t(j) * kBlock;
+                if (g < ngroups) {
+                    MV m = {};
+                    if constexpr (MASKED) m = mv[g];
+                    fold(pv[g], m);
+                }
+            }
+        }
+    }
+    // horizontal fold of the lane's CPL accumulators, then the ragged tail cells
+    A amin = vmin[0], amax = vmax[0];
+#pragma unroll
+    for (int k = 1; k < CPL; ++k) {
+        amin = vmin[k] < amin ? vmin[k] : amin;
+        amax = vmax[k] > amax ? vmax[k] : amax;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kBlock) {
+            if (MASKED && !mask[i]) continue;
+            A key = acc_key<T>(p[i]);
+            amin = key < amin ? key : amin;
+            amax = key > amax ? key : amax;
+        }
+    }
+    int64_t kmin = wave_min_i64(acc_to_i64<A>(amin));
+    int64_t kmax = wave_max_i64(acc_to_i64<A>(amax));
+    __shared__ int64_t s_min[kWavesPerBlock], s_max[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) { s_min[wave] = kmin; s_max[wave] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            kmin = s_min[w] < kmin ? s_min[w] : kmin;
+            kmax = s_max[w] > kmax ? s_max[w] : kmax;
+        }
+        partials[2 * size_t(blockIdx.x)] = kmin;
+        partials[2 * size_t(blockIdx.x) + 1] = kmax;
+    }
+}
+
+// Same reduction, cell-wise loads: any alignment.
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(kBlock) void k_min_max_partials_cellwise(const T* __restrict__ p, const uint8_t* __restrict__ mask,
+                                                                      size_t n, int64_t* __restrict__ partials) {
+    using A = typename AccT<T>::type;
+    A amin = acc_key<T>(Limits<T>::hi), amax = acc_key<T>(Limits<T>::lo);
+    const size_t stride = size_t(gridDim.x) * kBlock;
+    for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        if (MASKED && !mask[i]) continue;
+        A key = acc_key<T>(p[i]);
+        amin = key < amin ? key : amin;
+        amax = key > amax ? key : amax;
+    }
+    int64_t kmin = wave_min_i64(acc_to_i64<A>(amin));
+    int64_t kmax = wave_max_i64(acc_to_i64<A>(amax));
+    __shared__ int64_t s_min[kWavesPerBlock], s_max[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) { s_min[wave] = kmin; s_max[wave] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            kmin = s_min[w] < kmin ? s_min[w] : kmin;
+            kmax = s_max[w] > kmax ? s_max[w] : kmax;
+        }
+        partials[2 * size_t(blockIdx.x)] = kmin;
+        partials[2 * size_t(blockIdx.x) + 1] = kmax;
+    }
+}
+
+// keys2 = {~min, max}: a MAX reduction over shards of both words is the global answer.
+__global__ __launch_bounds__(kBlock) void k_min_max_finalize(const int64_t* __restrict__ partials, int nparts,
+                                                             int64_t sentinel_min, int64_t sentinel_max,
+                                                             int64_t* __restrict__ keys2) {
+    int64_t kmin = sentinel_min, kmax = sentinel_max;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) {
+        int64_t a = partials[2 * i], b = partials[2 * i + 1];
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    kmin = wave_min_i64(kmin);
+    kmax = wave_max_i64(kmax);
+    __shared__ int64_t s_min[kWavesPerBlock], s_max[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) { s_min[wave] = kmin; s_max[wave] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            kmin = s_min[w] < kmin ? s_min[w] : kmin;
+            kmax = s_max[w] > kmax ? s_max[w] : kmax;
+        }
+        keys2[0] = ~kmin;
+        keys2[1] = kmax;
+    }
+}
+
+// ---- Mask::counts: bytes are 0/1, so the count of true cells is the byte sum.
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int U>
+__global__ __launch_bounds__(kBlock) void k_mask_count_partials(const uint8_t* __restrict__ m, size_t n,
+                                                                uint64_t* __restrict__ partials, bool aligned) {
+    uint64_t cnt = 0;
+    if (aligned) {
+        const size_t ngroups = n / 16;
+        constexpr size_t TILE = size_t(kBlock) * U;
+        const size_t ntiles = (ngroups + TILE - 1) / TILE;
+        const u32x4* __restrict__ mv = reinterpret_cast<const u32x4*>(m);
+        uint32_t c32 = 0;
+        for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const size_t base = tile * TILE + threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const size_t g = base + size_t(j) * kBlock;
+                if (g < ngroups) {
+                    u32x4 x = __builtin_nontemporal_load(mv + g);
+                    c32 += __builtin_popcount(x.x & 0x01010101u) + __builtin_popcount(x.y & 0x01010101u) +
+                           __builtin_popcount(x.z & 0x01010101u) + __builtin_popcount(x.w & 0x01010101u);
+                }
+            }
+            if (c32 > 0x7fff0000u) { cnt += c32; c32 = 0; }
+        }
+        cnt += c32;
+        if (blockIdx.x == 0)
+            for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) cnt += m[i] & 1;
+    } else {
+        const size_t stride = size_t(gridDim.x) * kBlock;
+        for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) cnt += m[i] & 1;
+    }
+    cnt = wave_sum_u64(cnt);
+    __shared__ uint64_t s_cnt[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) cnt += s_cnt[w];
+        partials[blockIdx.x] = cnt;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_mask_count_finalize(const uint64_t* __restrict__ partials, int nparts,
+                                                                uint64_t n, uint64_t* __restrict__ counts2) {
+    uint64_t cnt = 0;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) cnt += partials[i];
+    cnt = wave_sum_u64(cnt);
+    __shared__ uint64_t s_cnt[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) cnt += s_cnt[w];
+        counts2[0] = cnt;
+        counts2[1] = n - cnt;
+    }
+}
+
+}  // namespace ecd

@@ -1,0 +1,65 @@
+// ec_runtime.hpp — process-wide state shared by the translation units of
+// liberased_cells_hip.so: error reporting, launch-shape knobs, reduction scratch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "erased_cells.h"
+
+namespace ecd {
+
+// Compile-time launch shape of the binary-arithmetic kernels; chosen from the
+// A/B runs recorded in profiles/ (tools/tune_binop.hip).
+constexpr int kBinopU = 8;         // chunks of 128 cells per wave per tile
+constexpr bool kNtStore = true;    // streaming f64 output: 2.1 GB ≫ 256 MiB Infinity Cache
+constexpr bool kNtLoad = false;
+constexpr int kMapU = 4;           // groups per lane per tile for the map kernels
+constexpr int kReduceU = 4;
+constexpr int kMaxReduceBlocks = 4096;
+
+struct Tuning {
+    int binop_variant = 0;  // 0 = direct narrow loads, 1 = LDS-staged narrow operands
+    int bpc = 0;            // blocks per CU cap for element-wise grids; 0 = one block per tile
+    int reduce_bpc = 8;     // blocks per CU for reductions (partials are per block)
+};
+
+Tuning& tuning();
+int device_cus();
+
+ec_status set_error(ec_status code, const char* fmt, ...);
+ec_status set_narrowing(int src, int dst);
+ec_status check_launch(const char* what);
+ec_status check_hip(hipError_t e, const char* what);
+
+inline bool aligned16(const void* a, const void* b, const void* c) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15u) == 0;
+}
+
+// Grid for `tiles` block tiles: all of them, or capped at bpc blocks per CU
+// (the kernels grid-stride over tiles either way).
+inline unsigned grid_for(size_t tiles, int bpc) {
+    if (tiles < 1) tiles = 1;
+    size_t cap = bpc > 0 ? size_t(device_cus()) * size_t(bpc) : size_t(0x7fffffff);
+    return static_cast<unsigned>(tiles < cap ? tiles : cap);
+}
+
+// Per-stream scratch for reduction partials (device) and results (pinned host).
+struct Scratch {
+    int64_t* dev = nullptr;    // 2*kMaxReduceBlocks partials + 4 result words
+    int64_t* host = nullptr;   // 4 words, pinned
+    int64_t* dev_result() const { return dev + 2 * kMaxReduceBlocks; }
+};
+ec_status get_scratch(hipStream_t s, Scratch* out);
+
+// binary arithmetic, one translation unit per op
+template <int OP>
+ec_status dispatch_binop(int lt, const void* l, int rt, const void* r, size_t n, double* out, hipStream_t s);
+template <int OP>
+ec_status dispatch_masked_binop(int lt, const void* l, const uint8_t* lm, int rt, const void* r, const uint8_t* rm,
+                                size_t n, double* out, uint8_t* om, hipStream_t s);
+template <int OP>
+ec_status dispatch_binop_scalar(int lt, const void* l, double rhs, size_t n, double* out, hipStream_t s);
+
+}  // namespace ecd

@@ -1,0 +1,14 @@
+"""erased_cells_hip — Python plumbing over liberased_cells_hip.so (MI355X / gfx950).
+
+`_ffi`     ctypes binding of include/erased_cells.h (fails loudly if the .so is missing)
+`buffer`   host mirror of CellBuffer / MaskedCellBuffer / Mask / NoData / CellValue
+`sharded`  row-block sharding across ranks + the RCCL all-reduce for min/max and counts
+"""
+from . import _ffi
+from ._ffi import EcError, NarrowingError, build, lib
+from .buffer import (ADD, CELL_TYPES, CT_NAMES, DIV, MUL, NP_DTYPES, SUB, CellBuffer, CellValue, DeviceMem,
+                     Float32, Float64, Int8, Int16, Int32, Int64, Mask, MaskedCellBuffer, NoData, UInt8,
+                     UInt16, UInt32, UInt64, can_fit_into, cell_type_of, init, mask_from_nodata, set_stream,
+                     stream, synchronize, union)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,133 @@
+"""ctypes binding of liberased_cells_hip.so (include/erased_cells.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent the
+import fails loudly, and every compute call raises unless a HIP device is bound.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+AMD_DIR = os.path.dirname(os.path.dirname(_PKG))          # erased-cells_amd/
+REPO = os.path.dirname(AMD_DIR)
+SO_PATH = os.path.join(AMD_DIR, "liberased_cells_hip.so")
+CSRC = os.path.join(AMD_DIR, "csrc")
+
+EC_OK, EC_ERR_NARROWING, EC_ERR_UNSUPPORTED_TYPE, EC_ERR_LENGTH, EC_ERR_HIP, EC_ERR_RCCL, EC_ERR_ARG, \
+    EC_ERR_NOT_INITIALIZED = range(8)
+
+
+class _Payload(C.Union):
+    _fields_ = [("u8", C.c_uint8), ("u16", C.c_uint16), ("u32", C.c_uint32), ("u64", C.c_uint64),
+                ("i8", C.c_int8), ("i16", C.c_int16), ("i32", C.c_int32), ("i64", C.c_int64),
+                ("f32", C.c_float), ("f64", C.c_double), ("bits", C.c_uint64)]
+
+
+class EcValue(C.Structure):
+    """ec_value: 16-byte tagged scalar (CellValue, src/value.rs:12-20)."""
+    _fields_ = [("dtype", C.c_uint8), ("pad_", C.c_uint8 * 7), ("v", _Payload)]
+
+
+VP, SZ, I32, U8P = C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p
+PV = C.POINTER(EcValue)
+
+# name -> (restype, argtypes): every symbol include/erased_cells.h declares.
+SIGNATURES = {
+    "ec_union": (C.c_uint8, [C.c_uint8, C.c_uint8]),
+    "ec_can_fit_into": (I32, [C.c_uint8, C.c_uint8]),
+    "ec_size_of": (SZ, [C.c_uint8]),
+    "ec_neg_result_type": (C.c_uint8, [C.c_uint8]),
+    "ec_min_value": (I32, [C.c_uint8, PV]),
+    "ec_max_value": (I32, [C.c_uint8, PV]),
+    "ec_nodata_default": (I32, [C.c_uint8, PV]),
+    "ec_value_convert": (I32, [PV, C.c_uint8, PV]),
+    "ec_value_to_f64": (C.c_double, [PV]),
+    "ec_shard_range": (I32, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "ec_abi_version": (I32, []),
+    "ec_init": (I32, [I32]),
+    "ec_shutdown": (I32, []),
+    "ec_last_error_string": (C.c_char_p, []),
+    "ec_last_narrowing": (I32, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
+    "ec_device_info": (I32, [C.POINTER(I32), C.POINTER(C.c_uint64), C.c_char_p, SZ]),
+    "ec_alloc": (I32, [C.POINTER(VP), SZ]),
+    "ec_free": (I32, [VP]),
+    "ec_upload": (I32, [VP, VP, SZ, VP]),
+    "ec_download": (I32, [VP, VP, SZ, VP]),
+    "ec_copy": (I32, [VP, VP, SZ, VP]),
+    "ec_stream_create": (I32, [C.POINTER(VP)]),
+    "ec_stream_destroy": (I32, [VP]),
+    "ec_stream_sync": (I32, [VP]),
+    "ec_binop": (I32, [I32, C.c_uint8, VP, C.c_uint8, VP, SZ, VP, VP]),
+    "ec_binop_scalar": (I32, [I32, C.c_uint8, VP, SZ, PV, VP, VP]),
+    "ec_masked_binop": (I32, [I32, C.c_uint8, VP, U8P, C.c_uint8, VP, U8P, SZ, VP, U8P, VP]),
+    "ec_neg": (I32, [C.c_uint8, VP, SZ, VP, VP]),
+    "ec_convert": (I32, [C.c_uint8, VP, C.c_uint8, VP, SZ, VP]),
+    "ec_fill": (I32, [C.c_uint8, VP, SZ, PV, VP]),
+    "ec_min_max": (I32, [C.c_uint8, VP, U8P, SZ, PV, PV, VP]),
+    "ec_min_max_keys": (I32, [C.c_uint8, VP, U8P, SZ, VP, VP]),
+    "ec_min_max_decode": (I32, [C.c_uint8, C.POINTER(C.c_int64), PV, PV]),
+    "ec_mask_from_nodata": (I32, [C.c_uint8, VP, SZ, PV, U8P, VP]),
+    "ec_mask_select": (I32, [C.c_uint8, VP, U8P, SZ, PV, VP, VP]),
+    "ec_mask_and": (I32, [U8P, U8P, SZ, U8P, VP]),
+    "ec_mask_or": (I32, [U8P, U8P, SZ, U8P, VP]),
+    "ec_mask_not": (I32, [U8P, SZ, U8P, VP]),
+    "ec_mask_counts": (I32, [U8P, SZ, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), VP]),
+    "ec_mask_counts_device": (I32, [U8P, SZ, VP, VP]),
+    "ec_synth_fill": (I32, [C.c_uint8, VP, SZ, C.c_uint64, C.c_uint64, C.c_double, C.c_double, VP]),
+    "ec_synth_mask": (I32, [U8P, SZ, C.c_uint64, C.c_uint64, C.c_uint32, VP]),
+    "ec_tune_set": (I32, [C.c_char_p, C.c_int64]),
+}
+
+
+def build(force: bool = False, jobs: int = 8) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, f"-j{jobs}", "-s"]
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean", "-s"])
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              f"(or `make -C {CSRC}`); there is no CPU fallback")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class EcError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[ec_status {status}] {message}")
+        self.status = status
+
+
+class NarrowingError(EcError):
+    """Error::NarrowingError{src,dst} (src/error.rs:14-15)."""
+
+    def __init__(self, message: str, src: int, dst: int):
+        super().__init__(EC_ERR_NARROWING, message)
+        self.src, self.dst = src, dst
+
+
+def check(status: int) -> None:
+    if status == EC_OK:
+        return
+    L = lib()
+    msg = (L.ec_last_error_string() or b"").decode()
+    if status == EC_ERR_NARROWING:
+        s, d = C.c_uint8(), C.c_uint8()
+        L.ec_last_narrowing(C.byref(s), C.byref(d))
+        raise NarrowingError(msg, s.value, d.value)
+    raise EcError(status, msg)

@@ -1,0 +1,652 @@
+"""Python host mirror of the reference's buffer API over the C ABI.
+
+Same names, argument meaning and error behaviour as `CellBuffer` /
+`MaskedCellBuffer` / `Mask` / `NoData` / `CellValue` / `CellType`
+(src/buffer.rs, src/masked/*.rs, src/value.rs, src/ctype.rs), so that the parity
+tests read like the reference's own tests.  Buffers live in HBM between
+operations (`from_vec` uploads once, `to_vec` downloads); every operator body is
+one call into liberased_cells_hip.so.  The host keeps what the reference's host
+code keeps: the dtype-erased dispatch tag, zip truncation (src/buffer.rs:327),
+the empty-result-is-UInt8 rule (src/buffer.rs:233-234) and the length asserts.
+
+This module is test/bench plumbing; the compiled host mirror is
+erased-cells_amd/host/erased_cells.hpp and the Rust binding is in INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import EcValue, check, lib
+
+# CellType (src/ctype.rs:11-20; order of with_ct!, src/lib.rs:89-98)
+UInt8, UInt16, UInt32, UInt64, Int8, Int16, Int32, Int64, Float32, Float64 = range(10)
+CELL_TYPES = list(range(10))
+CT_NAMES = ["UInt8", "UInt16", "UInt32", "UInt64", "Int8", "Int16", "Int32", "Int64", "Float32", "Float64"]
+NP_DTYPES = [np.dtype(d) for d in (np.uint8, np.uint16, np.uint32, np.uint64, np.int8, np.int16, np.int32,
+                                   np.int64, np.float32, np.float64)]
+ADD, SUB, MUL, DIV = range(4)
+
+_stream: Optional[int] = None  # hipStream_t handle; None = default stream
+
+
+def init(device: int = 0) -> None:
+    check(lib().ec_init(device))
+
+
+def set_stream(handle: Optional[int]) -> None:
+    """Route subsequent launches to `handle` (e.g. torch.cuda.current_stream().cuda_stream)."""
+    global _stream
+    _stream = handle
+
+
+def stream() -> Optional[int]:
+    return _stream
+
+
+def synchronize() -> None:
+    check(lib().ec_stream_sync(_stream))
+
+
+def cell_type_of(dtype) -> int:
+    dt = np.dtype(dtype)
+    for i, d in enumerate(NP_DTYPES):
+        if d == dt:
+            return i
+    raise TypeError(f"no CellType for dtype {dt}")  # e.g. isize is not CellEncoding (encoding.rs:5-8)
+
+
+def union(a: int, b: int) -> int:
+    return lib().ec_union(a, b)
+
+
+def can_fit_into(a: int, b: int) -> bool:
+    return bool(lib().ec_can_fit_into(a, b))
+
+
+# --------------------------------------------------------------------------- CellValue
+class CellValue:
+    """Scalar with a run-time cell type (src/value.rs:12-20)."""
+
+    __slots__ = ("ct", "value")
+
+    def __init__(self, ct: int, value):
+        self.ct = ct
+        self.value = value if isinstance(value, np.generic) and value.dtype == NP_DTYPES[ct] else \
+            np.array([value]).astype(NP_DTYPES[ct])[0]
+
+    @staticmethod
+    def new(x, ct: Optional[int] = None) -> "CellValue":
+        """`x.into()`: numpy scalars keep their type; Python ints are i32, floats f64 (Rust literal defaults)."""
+        if isinstance(x, CellValue):
+            return x
+        if ct is not None:
+            return CellValue(ct, x)
+        if isinstance(x, np.generic):
+            return CellValue(cell_type_of(x.dtype), x)
+        if isinstance(x, bool):
+            raise TypeError("bool is not a CellEncoding")
+        if isinstance(x, int):
+            return CellValue(Int32, x)
+        if isinstance(x, float):
+            return CellValue(Float64, x)
+        raise TypeError(f"cannot convert {type(x)} into CellValue")
+
+    def cell_type(self) -> int:
+        return self.ct
+
+    def bits(self) -> int:
+        return int.from_bytes(np.array([self.value], dtype=NP_DTYPES[self.ct]).tobytes(), "little")
+
+    def to_ec(self) -> EcValue:
+        v = EcValue()
+        v.dtype = self.ct
+        v.v.bits = self.bits()
+        return v
+
+    @staticmethod
+    def from_ec(v: EcValue) -> "CellValue":
+        n = NP_DTYPES[v.dtype].itemsize
+        raw = int(v.v.bits & ((1 << (8 * n)) - 1)).to_bytes(n, "little")
+        return CellValue(v.dtype, np.frombuffer(raw, dtype=NP_DTYPES[v.dtype])[0])
+
+    def convert(self, ct: int) -> "CellValue":
+        """CellValue::convert (value.rs:74-98): NarrowingError unless can_fit_into."""
+        out = EcValue()
+        src = self.to_ec()
+        check(lib().ec_value_convert(C.byref(src), ct, C.byref(out)))
+        return CellValue.from_ec(out)
+
+    def get(self, ct: int):
+        return self.convert(ct).value
+
+    def to_f64(self) -> float:
+        src = self.to_ec()
+        return lib().ec_value_to_f64(C.byref(src))
+
+    def _key(self, ct: int) -> int:
+        c = self.convert(ct)
+        if NP_DTYPES[ct].kind != "f":
+            return int(c.value)
+        n = NP_DTYPES[ct].itemsize * 8
+        b = c.bits()
+        if b >> (n - 1):
+            b = b - (1 << n)  # as signed
+            b ^= (1 << (n - 1)) - 1
+        return b
+
+    def cmp(self, other: "CellValue") -> int:
+        """impl Ord for CellValue (value.rs:248-265): unify, ints natural, floats total_cmp."""
+        ct = union(self.ct, other.ct)
+        a, b = self._key(ct), other._key(ct)
+        return (a > b) - (a < b)
+
+    def __eq__(self, other):
+        return self.cmp(CellValue.new(other)) == 0
+
+    def __lt__(self, other):
+        return self.cmp(CellValue.new(other)) < 0
+
+    def __hash__(self):
+        return hash((self.ct, self.bits()))
+
+    def __repr__(self):
+        return f"{CT_NAMES[self.ct]}({self.value!r})"
+
+
+# --------------------------------------------------------------------------- device memory
+class DeviceMem:
+    """An HBM allocation (ec_alloc/ec_free), or a window into one (shards)."""
+
+    def __init__(self, nbytes: int, _parent: "DeviceMem" = None, _offset: int = 0):
+        self.nbytes = nbytes
+        self._parent = _parent
+        if _parent is not None:
+            self.ptr = (_parent.ptr or 0) + _offset if nbytes else None
+            self._owned = False
+        else:
+            p = C.c_void_p()
+            check(lib().ec_alloc(C.byref(p), nbytes))
+            self.ptr = p.value
+            self._owned = True
+
+    def window(self, offset: int, nbytes: int) -> "DeviceMem":
+        assert 0 <= offset and offset + nbytes <= self.nbytes
+        return DeviceMem(nbytes, _parent=self, _offset=offset)
+
+    def __del__(self):
+        if getattr(self, "_owned", False) and self.ptr:
+            try:
+                lib().ec_free(self.ptr)
+            except Exception:
+                pass
+            self.ptr = None
+
+
+def _upload(a: np.ndarray) -> DeviceMem:
+    a = np.ascontiguousarray(a)
+    mem = DeviceMem(a.nbytes)
+    if a.nbytes:
+        check(lib().ec_upload(mem.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes, _stream))
+    return mem
+
+
+def _download(mem: DeviceMem, dtype, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=dtype)
+    if out.nbytes:
+        check(lib().ec_download(out.ctypes.data_as(C.c_void_p), mem.ptr, out.nbytes, _stream))
+    return out
+
+
+def _scalar(x) -> CellValue:
+    return CellValue.new(x)
+
+
+# --------------------------------------------------------------------------- CellBuffer
+class CellBuffer:
+    """Device-resident `CellBuffer` (src/buffer.rs:12-55): a cell type tag + n cells in HBM."""
+
+    def __init__(self, ct: int, n: int, mem: DeviceMem):
+        self.ct, self.n, self.mem = ct, n, mem
+
+    # ---- constructors (BufferOps, src/lib.rs:104-163)
+    @staticmethod
+    def from_vec(data) -> "CellBuffer":
+        a = np.ascontiguousarray(data)
+        if a.dtype == np.dtype(np.int64) and not isinstance(data, np.ndarray):
+            a = a.astype(np.int32)  # Rust integer literals default to i32
+        return CellBuffer(cell_type_of(a.dtype), a.size, _upload(a.ravel()))
+
+    new = from_vec
+
+    @staticmethod
+    def with_defaults(length: int, ct: int) -> "CellBuffer":
+        return CellBuffer.fill(length, CellValue(ct, 0))
+
+    @staticmethod
+    def fill(length: int, value) -> "CellBuffer":
+        v = _scalar(value)
+        mem = DeviceMem(length * NP_DTYPES[v.ct].itemsize)
+        ev = v.to_ec()
+        check(lib().ec_fill(v.ct, mem.ptr, length, C.byref(ev), _stream))
+        return CellBuffer(v.ct, length, mem)
+
+    @staticmethod
+    def fill_via(length: int, f: Callable[[int], object], dtype) -> "CellBuffer":
+        return CellBuffer.from_vec(np.array([f(i) for i in range(length)], dtype=dtype))
+
+    @staticmethod
+    def empty(length: int, ct: int) -> "CellBuffer":
+        return CellBuffer(ct, length, DeviceMem(length * NP_DTYPES[ct].itemsize))
+
+    # ---- accessors
+    def len(self) -> int:
+        return self.n
+
+    __len__ = len
+
+    def is_empty(self) -> bool:
+        return self.n == 0
+
+    def cell_type(self) -> int:
+        return self.ct
+
+    def shard(self, cell_offset: int, cell_len: int) -> "CellBuffer":
+        """Contiguous window (row-block shard) of this buffer; no copy."""
+        sz = NP_DTYPES[self.ct].itemsize
+        return CellBuffer(self.ct, cell_len, self.mem.window(cell_offset * sz, cell_len * sz))
+
+    def get(self, index: int) -> CellValue:
+        if not 0 <= index < self.n:
+            raise IndexError(f"index out of bounds: the len is {self.n} but the index is {index}")  # Rust panics
+        sz = NP_DTYPES[self.ct].itemsize
+        return CellValue(self.ct, _download(self.mem.window(index * sz, sz), NP_DTYPES[self.ct], 1)[0])
+
+    def put(self, index: int, value) -> None:
+        v = _scalar(value).convert(self.ct)  # NarrowingError like buffer.rs:137
+        if not 0 <= index < self.n:
+            raise IndexError(f"index out of bounds: the len is {self.n} but the index is {index}")
+        sz = NP_DTYPES[self.ct].itemsize
+        a = np.array([v.value], dtype=NP_DTYPES[self.ct])
+        check(lib().ec_upload(self.mem.window(index * sz, sz).ptr, a.ctypes.data_as(C.c_void_p), sz, _stream))
+
+    def to_numpy(self) -> np.ndarray:
+        return _download(self.mem, NP_DTYPES[self.ct], self.n)
+
+    def clone(self) -> "CellBuffer":
+        out = CellBuffer.empty(self.n, self.ct)
+        check(lib().ec_copy(out.mem.ptr, self.mem.ptr, self.mem.nbytes, _stream))
+        return out
+
+    # ---- convert / to_vec / min_max (src/buffer.rs:150-185)
+    def convert(self, ct: int) -> "CellBuffer":
+        if ct == self.ct:
+            return self.clone()
+        if not can_fit_into(self.ct, ct):
+            check(lib().ec_convert(self.ct, None, ct, None, 0, _stream))  # raises NarrowingError{src,dst}
+        if self.n == 0:
+            return CellBuffer.empty(0, UInt8)  # collect() of nothing (buffer.rs:233-234)
+        out = CellBuffer.empty(self.n, ct)
+        check(lib().ec_convert(self.ct, self.mem.ptr, ct, out.mem.ptr, self.n, _stream))
+        return out
+
+    def to_vec(self, ct: Optional[int] = None) -> np.ndarray:
+        ct = self.ct if ct is None else ct
+        r = self.convert(ct)
+        if r.ct != ct:
+            raise AssertionError("danger::cast: cell types differ (empty convert yields UInt8, buffer.rs:443-444)")
+        return r.to_numpy()
+
+    def min_max(self) -> tuple[CellValue, CellValue]:
+        mn, mx = EcValue(), EcValue()
+        check(lib().ec_min_max(self.ct, self.mem.ptr, None, self.n, C.byref(mn), C.byref(mx), _stream))
+        return CellValue.from_ec(mn), CellValue.from_ec(mx)
+
+    # ---- arithmetic (src/buffer.rs:321-371)
+    def _binop(self, op: int, rhs) -> "CellBuffer":
+        if isinstance(rhs, CellBuffer):
+            n = min(self.n, rhs.n)  # zip (buffer.rs:327)
+            if n == 0:
+                return CellBuffer.empty(0, UInt8)
+            out = CellBuffer.empty(n, Float64)
+            check(lib().ec_binop(op, self.ct, self.mem.ptr, rhs.ct, rhs.mem.ptr, n, out.mem.ptr, _stream))
+            return out
+        v = _scalar(rhs).to_ec()  # RHS scalar (buffer.rs:346-352)
+        if self.n == 0:
+            return CellBuffer.empty(0, UInt8)
+        out = CellBuffer.empty(self.n, Float64)
+        check(lib().ec_binop_scalar(op, self.ct, self.mem.ptr, self.n, C.byref(v), out.mem.ptr, _stream))
+        return out
+
+    def __add__(self, rhs): return self._binop(ADD, rhs)
+    def __sub__(self, rhs): return self._binop(SUB, rhs)
+    def __mul__(self, rhs): return self._binop(MUL, rhs)
+    def __truediv__(self, rhs): return self._binop(DIV, rhs)
+
+    def __neg__(self) -> "CellBuffer":
+        if self.n == 0:
+            return CellBuffer.empty(0, UInt8)
+        out = CellBuffer.empty(self.n, lib().ec_neg_result_type(self.ct))
+        check(lib().ec_neg(self.ct, self.mem.ptr, self.n, out.mem.ptr, _stream))
+        return out
+
+    # ---- Ord / Eq (src/buffer.rs:373-436), host side after download
+    def cmp(self, other: "CellBuffer") -> int:
+        if self.ct != other.ct:
+            return (self.ct > other.ct) - (self.ct < other.ct)
+        a, b = _order_keys(self.to_numpy()), _order_keys(other.to_numpy())
+        n = min(a.size, b.size)
+        ne = np.flatnonzero(a[:n] != b[:n])
+        if ne.size:
+            i = int(ne[0])
+            return 1 if a[i] > b[i] else -1
+        return (a.size > b.size) - (a.size < b.size)
+
+    def __eq__(self, other):
+        return isinstance(other, CellBuffer) and self.cmp(other) == 0
+
+    def __lt__(self, other):
+        return self.cmp(other) < 0
+
+    def __gt__(self, other):
+        return self.cmp(other) > 0
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"{CT_NAMES[self.ct]}CellBuffer(len={self.n})"
+
+
+def _order_keys(a: np.ndarray) -> np.ndarray:
+    """Total-order keys: ints as themselves, floats per total_cmp (value.rs:260-261)."""
+    if a.dtype.kind != "f":
+        return a
+    it = np.int32 if a.dtype.itemsize == 4 else np.int64
+    ut = np.uint32 if a.dtype.itemsize == 4 else np.uint64
+    b = a.view(it)
+    sh = a.dtype.itemsize * 8 - 1
+    return b ^ ((b >> sh).view(ut) >> ut(1)).view(it)
+
+
+# --------------------------------------------------------------------------- NoData
+class NoData:
+    """NoData<T> (src/masked/nodata.rs:7-17)."""
+
+    NONE, DEFAULT, VALUE = range(3)
+
+    def __init__(self, kind: int, value=None):
+        self.kind, self._value = kind, value
+
+    @staticmethod
+    def none() -> "NoData":
+        return NoData(NoData.NONE)
+
+    @staticmethod
+    def default() -> "NoData":
+        return NoData(NoData.DEFAULT)
+
+    @staticmethod
+    def new(value) -> "NoData":
+        return NoData(NoData.VALUE, value)
+
+    def value(self, ct: int) -> Optional[CellValue]:
+        """NoData::value (nodata.rs:23-40) for T = ct."""
+        if self.kind == NoData.NONE:
+            return None
+        if self.kind == NoData.VALUE:
+            v = self._value
+            return v if isinstance(v, CellValue) and v.ct == ct else CellValue(ct, v.value if isinstance(v, CellValue) else v)
+        out = EcValue()
+        check(lib().ec_nodata_default(ct, C.byref(out)))
+        return CellValue.from_ec(out)
+
+
+# --------------------------------------------------------------------------- Mask
+class Mask:
+    """`Mask(Vec<bool>)` (src/masked/mask.rs:10-12): one byte per cell, 0 or 1, in HBM."""
+
+    def __init__(self, n: int, mem: DeviceMem):
+        self.n, self.mem = n, mem
+
+    @staticmethod
+    def new(values: Sequence[bool]) -> "Mask":
+        a = np.ascontiguousarray(np.asarray(values).astype(bool).astype(np.uint8))
+        return Mask(a.size, _upload(a))
+
+    @staticmethod
+    def fill(length: int, value: bool) -> "Mask":
+        mem = DeviceMem(length)
+        ev = CellValue(UInt8, 1 if value else 0).to_ec()
+        check(lib().ec_fill(UInt8, mem.ptr, length, C.byref(ev), _stream))
+        return Mask(length, mem)
+
+    @staticmethod
+    def fill_via(length: int, f: Callable[[int], bool]) -> "Mask":
+        return Mask.new([bool(f(i)) for i in range(length)])
+
+    @staticmethod
+    def empty(length: int) -> "Mask":
+        return Mask(length, DeviceMem(length))
+
+    def len(self) -> int:
+        return self.n
+
+    __len__ = len
+
+    def is_empty(self) -> bool:
+        return self.n == 0
+
+    def shard(self, cell_offset: int, cell_len: int) -> "Mask":
+        return Mask(cell_len, self.mem.window(cell_offset, cell_len))
+
+    def to_numpy(self) -> np.ndarray:
+        return _download(self.mem, np.uint8, self.n)
+
+    def get(self, index: int) -> bool:
+        if not 0 <= index < self.n:
+            raise IndexError(index)
+        return bool(_download(self.mem.window(index, 1), np.uint8, 1)[0])
+
+    def put(self, index: int, value: bool) -> None:
+        if not 0 <= index < self.n:
+            raise IndexError(index)
+        a = np.array([1 if value else 0], dtype=np.uint8)
+        check(lib().ec_upload(self.mem.window(index, 1).ptr, a.ctypes.data_as(C.c_void_p), 1, _stream))
+
+    def clone(self) -> "Mask":
+        out = Mask.empty(self.n)
+        check(lib().ec_copy(out.mem.ptr, self.mem.ptr, self.n, _stream))
+        return out
+
+    def counts(self) -> tuple[int, int]:
+        """(data, nodata) — mask.rs:72-80."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().ec_mask_counts(self.mem.ptr, self.n, C.byref(a), C.byref(b), _stream))
+        return a.value, b.value
+
+    def all(self, value: bool) -> bool:
+        t, f = self.counts()
+        return (f == 0) if value else (t == 0)
+
+    def __invert__(self) -> "Mask":  # Not for &Mask (mask.rs:111-116)
+        out = Mask.empty(self.n)
+        check(lib().ec_mask_not(self.mem.ptr, self.n, out.mem.ptr, _stream))
+        return out
+
+    def __and__(self, rhs: "Mask") -> "Mask":  # BitAnd for &Mask: zip -> shorter (mask.rs:129-140)
+        n = min(self.n, rhs.n)
+        out = Mask.empty(n)
+        check(lib().ec_mask_and(self.mem.ptr, rhs.mem.ptr, n, out.mem.ptr, _stream))
+        return out
+
+    def __or__(self, rhs: "Mask") -> "Mask":  # BitOr for &Mask (mask.rs:153-163)
+        n = min(self.n, rhs.n)
+        out = Mask.empty(n)
+        check(lib().ec_mask_or(self.mem.ptr, rhs.mem.ptr, n, out.mem.ptr, _stream))
+        return out
+
+    def __iand__(self, rhs: "Mask") -> "Mask":  # BitAnd for Mask (owned, in place; lhs length kept — mask.rs:118-127)
+        check(lib().ec_mask_and(self.mem.ptr, rhs.mem.ptr, min(self.n, rhs.n), self.mem.ptr, _stream))
+        return self
+
+    def __ior__(self, rhs: "Mask") -> "Mask":  # mask.rs:142-151
+        check(lib().ec_mask_or(self.mem.ptr, rhs.mem.ptr, min(self.n, rhs.n), self.mem.ptr, _stream))
+        return self
+
+    def __eq__(self, other):
+        return isinstance(other, Mask) and self.n == other.n and np.array_equal(self.to_numpy(), other.to_numpy())
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"Mask(len={self.n})"
+
+
+# --------------------------------------------------------------------------- MaskedCellBuffer
+class MaskedCellBuffer:
+    """`MaskedCellBuffer(CellBuffer, Mask)` (src/masked/masked_buffer.rs:39-41)."""
+
+    def __init__(self, buffer: CellBuffer, mask: Mask):
+        if buffer.len() != mask.len():
+            raise AssertionError("Mask and buffer must have the same length.")  # masked_buffer.rs:48-53
+        self._buf, self._mask = buffer, mask
+
+    new = None  # set below (classmethod-style alias needs the class)
+
+    @staticmethod
+    def from_vec(data) -> "MaskedCellBuffer":
+        b = CellBuffer.from_vec(data)
+        return MaskedCellBuffer(b, Mask.fill(b.len(), True))
+
+    @staticmethod
+    def from_buffer(b: CellBuffer) -> "MaskedCellBuffer":  # From<CellBuffer> (masked_buffer.rs:250-255)
+        return MaskedCellBuffer(b, Mask.fill(b.len(), True))
+
+    @staticmethod
+    def from_vec_with_nodata(data, nodata: NoData) -> "MaskedCellBuffer":
+        """masked_buffer.rs:62-71: mask[i] = !(data[i] == nodata) under total-order equality."""
+        b = CellBuffer.from_vec(data)
+        return MaskedCellBuffer(b, mask_from_nodata(b, nodata))
+
+    @staticmethod
+    def with_defaults(length: int, ct: int) -> "MaskedCellBuffer":
+        return MaskedCellBuffer(CellBuffer.with_defaults(length, ct), Mask.fill(length, True))
+
+    @staticmethod
+    def fill(length: int, value) -> "MaskedCellBuffer":
+        return MaskedCellBuffer(CellBuffer.fill(length, value), Mask.fill(length, True))
+
+    @staticmethod
+    def fill_via(length: int, f, dtype) -> "MaskedCellBuffer":
+        return MaskedCellBuffer(CellBuffer.fill_via(length, f, dtype), Mask.fill(length, True))
+
+    @staticmethod
+    def fill_with_mask_via(length: int, mv: Callable[[int], tuple], dtype) -> "MaskedCellBuffer":
+        pairs = [mv(i) for i in range(length)]
+        return MaskedCellBuffer(CellBuffer.from_vec(np.array([p[0] for p in pairs], dtype=dtype)),
+                                Mask.new([p[1] for p in pairs]))
+
+    def buffer(self) -> CellBuffer:
+        return self._buf
+
+    def mask(self) -> Mask:
+        return self._mask
+
+    def len(self) -> int:
+        return self._buf.len()
+
+    __len__ = len
+
+    def cell_type(self) -> int:
+        return self._buf.cell_type()
+
+    def shard(self, cell_offset: int, cell_len: int) -> "MaskedCellBuffer":
+        return MaskedCellBuffer(self._buf.shard(cell_offset, cell_len), self._mask.shard(cell_offset, cell_len))
+
+    def get(self, index: int) -> CellValue:
+        return self._buf.get(index)
+
+    def put(self, index: int, value) -> None:
+        self._buf.put(index, value)
+
+    def get_masked(self, index: int) -> Optional[CellValue]:
+        return self._buf.get(index) if self._mask.get(index) else None
+
+    def get_with_mask(self, index: int) -> tuple[CellValue, bool]:
+        return self._buf.get(index), self._mask.get(index)
+
+    def put_with_mask(self, index: int, value, mask: bool) -> None:
+        self.put(index, value)
+        self._mask.put(index, mask)
+
+    def counts(self) -> tuple[int, int]:
+        return self._mask.counts()
+
+    def convert(self, ct: int) -> "MaskedCellBuffer":
+        return MaskedCellBuffer(self._buf.convert(ct), self._mask.clone())
+
+    def to_vec(self, ct: Optional[int] = None) -> np.ndarray:
+        return self._buf.to_vec(ct)
+
+    def to_vec_with_nodata(self, ct: int, no_data: NoData) -> np.ndarray:
+        """masked_buffer.rs:137-152: convert to T, then masked cells become no_data.value()."""
+        conv = self._buf.convert(ct)
+        if conv.ct != ct:
+            raise AssertionError("danger::cast: cell types differ")
+        nd = no_data.value(ct)
+        if nd is None:
+            return conv.to_numpy()
+        out = CellBuffer.empty(conv.n, ct)
+        ev = nd.to_ec()
+        check(lib().ec_mask_select(ct, conv.mem.ptr, self._mask.mem.ptr, conv.n, C.byref(ev), out.mem.ptr, _stream))
+        return out.to_numpy()
+
+    def min_max(self) -> tuple[CellValue, CellValue]:
+        mn, mx = EcValue(), EcValue()
+        check(lib().ec_min_max(self.cell_type(), self._buf.mem.ptr, self._mask.mem.ptr, self.len(),
+                               C.byref(mn), C.byref(mx), _stream))
+        return CellValue.from_ec(mn), CellValue.from_ec(mx)
+
+    # ---- arithmetic (src/masked/masked_buffer.rs:323-383)
+    def _binop(self, op: int, rhs) -> "MaskedCellBuffer":
+        if isinstance(rhs, MaskedCellBuffer):
+            n = min(self.len(), rhs.len())
+            if n == 0:
+                return MaskedCellBuffer(CellBuffer.empty(0, UInt8), Mask.empty(0))
+            out, om = CellBuffer.empty(n, Float64), Mask.empty(n)
+            check(lib().ec_masked_binop(op, self._buf.ct, self._buf.mem.ptr, self._mask.mem.ptr,
+                                        rhs._buf.ct, rhs._buf.mem.ptr, rhs._mask.mem.ptr, n,
+                                        out.mem.ptr, om.mem.ptr, _stream))
+            return MaskedCellBuffer(out, om)
+        return MaskedCellBuffer(self._buf._binop(op, rhs), self._mask.clone())  # scalar: mask carried over (:353-364)
+
+    def __add__(self, rhs): return self._binop(ADD, rhs)
+    def __sub__(self, rhs): return self._binop(SUB, rhs)
+    def __mul__(self, rhs): return self._binop(MUL, rhs)
+    def __truediv__(self, rhs): return self._binop(DIV, rhs)
+
+    def __neg__(self) -> "MaskedCellBuffer":
+        return MaskedCellBuffer(-self._buf, self._mask.clone())
+
+    def __eq__(self, other):  # derived PartialEq (masked_buffer.rs:39): buffer (all cells) and mask
+        return isinstance(other, MaskedCellBuffer) and self._buf == other._buf and self._mask == other._mask
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"{CT_NAMES[self.cell_type()]}MaskedCellBuffer(len={self.len()})"
+
+
+MaskedCellBuffer.new = staticmethod(lambda buffer, mask: MaskedCellBuffer(buffer, mask))
+
+
+def mask_from_nodata(b: CellBuffer, nodata: NoData) -> Mask:
+    m = Mask.empty(b.len())
+    nd = nodata.value(b.ct)
+    ev = nd.to_ec() if nd is not None else None
+    check(lib().ec_mask_from_nodata(b.ct, b.mem.ptr, b.len(), C.byref(ev) if ev is not None else None,
+                                    m.mem.ptr, _stream))
+    return m

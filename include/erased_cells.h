@@ -1,0 +1,192 @@
+/*
+ * erased_cells.h — C ABI of liberased_cells_hip.so: the MI355X (gfx950) drop-in
+ * for the per-cell arithmetic path of the Rust crate `erased-cells` 0.1.1.
+ *
+ * The reference has no FFI seam of its own; the seam is its operator/trait
+ * surface.  Each entry point below replaces the BODY of one reference function
+ * (cited as path:line relative to the reference tree); the host language keeps
+ * the dtype-erased dispatch (`with_ct!`, src/lib.rs:85-101) and the shape rules
+ * (zip truncation, empty -> UInt8, length asserts) and calls in here with plain
+ * device pointers and sizes.  INTEGRATION.md shows the Rust `extern "C"` block
+ * and the operator impls a maintainer would add.
+ *
+ * Conventions
+ *  - Every `const void*` / `void*` data argument is a DEVICE pointer (ec_alloc,
+ *    hipMalloc or any other HIP allocation) unless the name says `host`.
+ *  - Inputs are never written.  Outputs are caller-allocated; the library keeps
+ *    no hidden buffers except a small per-stream scratch for reduction partials.
+ *  - All compute entry points are asynchronous on `stream` (a hipStream_t; NULL
+ *    = the default stream) except those documented as "synchronous result".
+ *  - Every function returns ec_status; EC_OK == 0.  No exceptions cross the ABI.
+ *    ec_last_error_string() gives the thread-local detail of the last failure.
+ *  - dtype codes are `CellType as u8` (src/ctype.rs:11-20, order of
+ *    src/lib.rs:89-98): UInt8=0 .. Float64=9.
+ *  - Masks are `Vec<bool>` images: one byte per cell, 0 or 1 (src/masked/mask.rs:10-12).
+ */
+#ifndef ERASED_CELLS_H
+#define ERASED_CELLS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EC_ABI_VERSION 1
+
+typedef int32_t ec_status;
+enum {
+    EC_OK = 0,
+    EC_ERR_NARROWING = 1,        /* Error::NarrowingError{src,dst}      src/error.rs:14-15 */
+    EC_ERR_UNSUPPORTED_TYPE = 2, /* Error::UnsupportedCellTypeError     src/error.rs:16-17 */
+    EC_ERR_LENGTH = 3,           /* the reference panics (assert_eq! masked_buffer.rs:48-53) */
+    EC_ERR_HIP = 4,              /* a HIP runtime call failed */
+    EC_ERR_RCCL = 5,             /* reserved for the collective layer */
+    EC_ERR_ARG = 6,              /* null pointer / bad enum */
+    EC_ERR_NOT_INITIALIZED = 7
+};
+
+/* CellType (src/ctype.rs:11-20). */
+typedef uint8_t ec_dtype;
+enum {
+    EC_U8 = 0, EC_U16 = 1, EC_U32 = 2, EC_U64 = 3,
+    EC_I8 = 4, EC_I16 = 5, EC_I32 = 6, EC_I64 = 7,
+    EC_F32 = 8, EC_F64 = 9, EC_NTYPES = 10
+};
+
+/* Add/Sub/Mul/Div of cb_bin_op! (src/buffer.rs:355-358). */
+typedef int32_t ec_op;
+enum { EC_ADD = 0, EC_SUB = 1, EC_MUL = 2, EC_DIV = 3 };
+
+/* CellValue (src/value.rs:12-20): tag + payload, 16 bytes. */
+typedef struct ec_value {
+    uint8_t dtype;
+    uint8_t pad_[7];
+    union {
+        uint8_t u8; uint16_t u16; uint32_t u32; uint64_t u64;
+        int8_t i8; int16_t i16; int32_t i32; int64_t i64;
+        float f32; double f64;
+        uint64_t bits;
+    } v;
+} ec_value;
+
+typedef void *ec_stream; /* hipStream_t */
+
+/* ---------------------------------------------------------------- *
+ * Type lattice — pure host functions, no device needed.
+ * ---------------------------------------------------------------- */
+ec_dtype ec_union(ec_dtype a, ec_dtype b);          /* CellType::union        src/ctype.rs:99-126  */
+int32_t ec_can_fit_into(ec_dtype src, ec_dtype dst); /* CellType::can_fit_into src/ctype.rs:129-131 */
+size_t ec_size_of(ec_dtype t);                      /* CellType::size_of      src/ctype.rs:87-96   */
+ec_dtype ec_neg_result_type(ec_dtype t);            /* result variant of Neg  src/value.rs:224-240 */
+ec_status ec_min_value(ec_dtype t, ec_value *out);  /* CellType::min_value    src/ctype.rs:158-167 */
+ec_status ec_max_value(ec_dtype t, ec_value *out);  /* CellType::max_value    src/ctype.rs:170-179 */
+/* NoData::<T>::Default.value() (src/masked/nodata.rs:27-38): T::MIN / canonical NaN. */
+ec_status ec_nodata_default(ec_dtype t, ec_value *out);
+/* CellValue::convert (src/value.rs:74-98) for scalars (host). */
+ec_status ec_value_convert(const ec_value *v, ec_dtype dst, ec_value *out);
+/* CellValue::to_f64 (src/value.rs:145-156). */
+double ec_value_to_f64(const ec_value *v);
+
+/* Row-block sharding: rows [g*R/G, (g+1)*R/G) with the first
+ * R mod G shards one row longer; returns the shard's [cell_offset, cell_len). */
+ec_status ec_shard_range(uint64_t n_rows, uint64_t n_cols, uint32_t shard, uint32_t n_shards,
+                         uint64_t *cell_offset, uint64_t *cell_len);
+
+/* ---------------------------------------------------------------- *
+ * Runtime: device, memory, streams, errors.
+ * ---------------------------------------------------------------- */
+int32_t ec_abi_version(void);
+ec_status ec_init(int32_t device);   /* binds the calling process to `device`; idempotent */
+ec_status ec_shutdown(void);         /* frees reduction scratch */
+const char *ec_last_error_string(void);
+/* src/dst of the last EC_ERR_NARROWING on this thread (Error::NarrowingError fields). */
+ec_status ec_last_narrowing(ec_dtype *src, ec_dtype *dst);
+ec_status ec_device_info(int32_t *n_cu, uint64_t *hbm_bytes, char *name, size_t name_cap);
+
+ec_status ec_alloc(void **dptr, size_t bytes);
+ec_status ec_free(void *dptr);
+ec_status ec_upload(void *dst_dev, const void *src_host, size_t bytes, ec_stream stream);   /* From<Vec<T>> */
+ec_status ec_download(void *dst_host, const void *src_dev, size_t bytes, ec_stream stream); /* to_vec; waits for completion */
+ec_status ec_copy(void *dst_dev, const void *src_dev, size_t bytes, ec_stream stream);      /* Clone (buffer.rs:151-153) */
+ec_status ec_stream_create(ec_stream *out);
+ec_status ec_stream_destroy(ec_stream s);
+ec_status ec_stream_sync(ec_stream s);
+
+/* ---------------------------------------------------------------- *
+ * Element-wise arithmetic.  out[i] = f64(l[i]) op f64(r[i]), always Float64
+ * (src/value.rs:199-217).  `n` = min(len l, len r): the caller applies the zip
+ * truncation of src/buffer.rs:327.  n == 0 is a no-op.
+ * ---------------------------------------------------------------- */
+/* impl {Add,Sub,Mul,Div} for &CellBuffer — src/buffer.rs:324-329 */
+ec_status ec_binop(ec_op op, ec_dtype lt, const void *l, ec_dtype rt, const void *r,
+                   size_t n, double *out, ec_stream stream);
+/* impl $trt<R: Into<CellValue>> for CellBuffer — src/buffer.rs:346-352 */
+ec_status ec_binop_scalar(ec_op op, ec_dtype lt, const void *l, size_t n, const ec_value *rhs,
+                          double *out, ec_stream stream);
+/* impl $trt for &MaskedCellBuffer — src/masked/masked_buffer.rs:326-335: the
+ * buffer op over ALL cells and `lmask & rmask` (mask.rs:129-140) in one launch. */
+ec_status ec_masked_binop(ec_op op, ec_dtype lt, const void *l, const uint8_t *lmask,
+                          ec_dtype rt, const void *r, const uint8_t *rmask, size_t n,
+                          double *out, uint8_t *out_mask, ec_stream stream);
+/* impl Neg for &CellBuffer — src/buffer.rs:360-365 + src/value.rs:224-240.
+ * `out` holds n cells of ec_neg_result_type(t). Signed MIN wraps (release build). */
+ec_status ec_neg(ec_dtype t, const void *in, size_t n, void *out, ec_stream stream);
+/* BufferOps::convert — src/buffer.rs:150-167. EC_ERR_NARROWING iff
+ * !can_fit_into(st, dt), decided before any device work; st == dt is a copy. */
+ec_status ec_convert(ec_dtype st, const void *src, ec_dtype dt, void *dst, size_t n, ec_stream stream);
+/* BufferOps::fill — src/buffer.rs:79-88 (value->dtype must equal t). */
+ec_status ec_fill(ec_dtype t, void *dst, size_t n, const ec_value *value, ec_stream stream);
+
+/* ---------------------------------------------------------------- *
+ * min/max under the reference's total order (ints natural; floats total_cmp),
+ * folded from (T::MAX, T::MIN) — src/buffer.rs:169-173, masked:
+ * src/masked/masked_buffer.rs:208-217 (mask may be NULL).
+ * ---------------------------------------------------------------- */
+/* Synchronous result: waits for the stream, returns host values typed `t`. */
+ec_status ec_min_max(ec_dtype t, const void *p, const uint8_t *mask_or_null, size_t n,
+                     ec_value *mn, ec_value *mx, ec_stream stream);
+/* Asynchronous: writes two order-preserving int64 keys {~key(min), key(max)}
+ * to DEVICE memory `keys2_dev`, so that an element-wise MAX all-reduce across
+ * shards (RCCL over xGMI) followed by ec_min_max_decode gives the global answer. */
+ec_status ec_min_max_keys(ec_dtype t, const void *p, const uint8_t *mask_or_null, size_t n,
+                          int64_t *keys2_dev, ec_stream stream);
+ec_status ec_min_max_decode(ec_dtype t, const int64_t keys2_host[2], ec_value *mn, ec_value *mx);
+
+/* ---------------------------------------------------------------- *
+ * Masks.
+ * ---------------------------------------------------------------- */
+/* MaskedCellBuffer::from_vec_with_nodata — src/masked/masked_buffer.rs:62-71:
+ * mask[i] = !(x[i] == nd) under total-order (bitwise) equality, src/masked/nodata.rs:42-49.
+ * nd == NULL is NoData::None (all true). nd->dtype must equal t. */
+ec_status ec_mask_from_nodata(ec_dtype t, const void *p, size_t n, const ec_value *nd_or_null,
+                              uint8_t *mask, ec_stream stream);
+/* MaskedCellBuffer::to_vec_with_nodata — src/masked/masked_buffer.rs:143-151:
+ * out[i] = mask[i] ? p[i] : nd ; nd == NULL copies p. */
+ec_status ec_mask_select(ec_dtype t, const void *p, const uint8_t *mask, size_t n,
+                         const ec_value *nd_or_null, void *out, ec_stream stream);
+ec_status ec_mask_and(const uint8_t *l, const uint8_t *r, size_t n, uint8_t *out, ec_stream stream); /* mask.rs:118-140 */
+ec_status ec_mask_or(const uint8_t *l, const uint8_t *r, size_t n, uint8_t *out, ec_stream stream);  /* mask.rs:142-163 */
+ec_status ec_mask_not(const uint8_t *m, size_t n, uint8_t *out, ec_stream stream);                   /* mask.rs:103-116 */
+/* Mask::counts — src/masked/mask.rs:72-80. Synchronous result. */
+ec_status ec_mask_counts(const uint8_t *m, size_t n, uint64_t *n_true, uint64_t *n_false, ec_stream stream);
+/* Asynchronous: {n_true, n_false} to DEVICE memory (SUM all-reduce across shards). */
+ec_status ec_mask_counts_device(const uint8_t *m, size_t n, uint64_t *counts2_dev, ec_stream stream);
+
+/* ---------------------------------------------------------------- *
+ * Test/bench support (not part of the reference surface).
+ * ---------------------------------------------------------------- */
+/* x[i] = lo + splitmix64(seed ^ (base + i)) % (hi - lo + 1), t in {EC_U8, EC_U16, EC_F32}
+ * (for EC_F32: uniform on [lo, hi) as float from the same stream). */
+ec_status ec_synth_fill(ec_dtype t, void *dst, size_t n, uint64_t seed, uint64_t base,
+                        double lo, double hi, ec_stream stream);
+/* mask[i] = splitmix64(seed ^ (base+i)) % 100 >= pct_nodata */
+ec_status ec_synth_mask(uint8_t *dst, size_t n, uint64_t seed, uint64_t base, uint32_t pct_nodata, ec_stream stream);
+/* Launch-shape knobs for the element-wise kernels (tuning; 0 = library default). */
+ec_status ec_tune_set(const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ERASED_CELLS_H */

@@ -1,0 +1,289 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle on
+the same seeded inputs.  Bit-exact everywhere (integer, byte and index work, and
+the f64 results too — north_star allows 1 ULP on the f64 path; we hold it to 0).
+
+The only tolerance: a NaN whose sign/payload the reference itself does not pin —
+both operands NaN in a commutative op, where the x86 result depends on which
+operand the compiler put first — is compared by class.
+"""
+import numpy as np
+import pytest
+
+from oracle import eco
+from vectors import assert_f64_bits_equal, bits_of, rand_cells, rand_mask
+
+pytestmark = pytest.mark.gpu
+
+OPS = [eco.ADD, eco.SUB, eco.MUL, eco.DIV]
+NT = eco.NTYPES
+
+
+@pytest.fixture(scope="module")
+def ec():
+    import erased_cells_hip as ec
+    ec.init(0)
+    return ec
+
+
+def _both_nan(l, r):
+    with np.errstate(all="ignore"):
+        return np.isnan(l.astype(np.float64)) & np.isnan(r.astype(np.float64))
+
+
+# ---------------------------------------------------------------- binop: src/buffer.rs:324-329
+@pytest.mark.parametrize("lct", range(NT))
+def test_binop_all_pairs_bit_exact(ec, lct):
+    n = 8 * 1024 + 37  # several wave tiles + ragged tail
+    for rct in range(NT):
+        l, r = rand_cells(lct, n, 11), rand_cells(rct, n, 12)
+        dl, dr = ec.CellBuffer.from_vec(l), ec.CellBuffer.from_vec(r)
+        for op in OPS:
+            got = dl._binop(op, dr)
+            assert got.cell_type() == ec.Float64 and got.len() == n
+            exp = eco.f_binop(op, l, r)
+            loose = _both_nan(l, r) if op in (eco.ADD, eco.MUL) else None
+            assert_f64_bits_equal(got.to_numpy(), exp, nan_by_class_where=loose)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_binop_reference_shaped_oracle_and_variants(ec, variant):
+    """Both kernel variants (direct / LDS-staged) against the reference-shaped oracle."""
+    ec.lib().ec_tune_set(b"binop_variant", variant)
+    try:
+        n = 3000
+        for lct, rct in [(eco.U8, eco.U16), (eco.U16, eco.U8), (eco.I8, eco.F32), (eco.U64, eco.I64), (eco.F32, eco.F32),
+                         (eco.U8, eco.U8), (eco.I16, eco.U32), (eco.F64, eco.U16)]:
+            l, r = rand_cells(lct, n, 21), rand_cells(rct, n, 22)
+            for op in OPS:
+                got = ec.CellBuffer.from_vec(l)._binop(op, ec.CellBuffer.from_vec(r)).to_numpy()
+                loose = _both_nan(l, r) if op in (eco.ADD, eco.MUL) else None
+                assert_f64_bits_equal(got, eco.binop(op, l, r), nan_by_class_where=loose)
+    finally:
+        ec.lib().ec_tune_set(b"binop_variant", 0)
+
+
+@pytest.mark.parametrize("bpc", [0, 2])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_binop_lengths_tails_and_alignment(ec, variant, bpc):
+    """Ragged sizes around every tile boundary, zip truncation, and odd cell offsets
+    (row-block windows that are not 16-byte aligned take the cell-wise kernel)."""
+    ec.lib().ec_tune_set(b"binop_variant", variant)
+    ec.lib().ec_tune_set(b"bpc", bpc)
+    try:
+        big = 2 * 1024 * 1024 + 5
+        l, r = eco.fill_u8(big, 0x5EED0001), eco.fill_u16(big, 0x5EED0002, lo=0)  # zeros in the divisor: 0/0, x/0
+        dl, dr = ec.CellBuffer.from_vec(l), ec.CellBuffer.from_vec(r)
+        for n in [1, 2, 3, 63, 64, 127, 128, 129, 255, 256, 1023, 1024, 1025, 2047, 2048, 4095, 4096, 4097, 8191, 8193,
+                  65536 + 1, 1024 * 1024 - 1, big]:
+            got = (dl.shard(0, n) / dr.shard(0, n)).to_numpy()
+            assert_f64_bits_equal(got, eco.f_binop(eco.DIV, l[:n], r[:n]))
+        for off_l, off_r, n in [(1, 0, 5000), (0, 1, 5000), (3, 5, 4097), (8, 8, 9000), (16, 8, 70000), (16, 32, 70001)]:
+            got = (dl.shard(off_l, n) / dr.shard(off_r, n)).to_numpy()
+            assert_f64_bits_equal(got, eco.f_binop(eco.DIV, l[off_l:off_l + n], r[off_r:off_r + n]))
+        # zip: result length is the shorter operand's (buffer.rs:327)
+        got = dl.shard(0, 700) - dr.shard(0, 333)
+        assert got.len() == 333
+        assert_f64_bits_equal(got.to_numpy(), eco.f_binop(eco.SUB, l[:700], r[:333]))
+        # empty result is a UInt8 buffer (buffer.rs:233-234)
+        e = dl.shard(0, 0) + dr
+        assert e.cell_type() == ec.UInt8 and e.len() == 0
+    finally:
+        ec.lib().ec_tune_set(b"binop_variant", 0)
+        ec.lib().ec_tune_set(b"bpc", 0)
+
+
+def test_div_by_zero_and_nan_policy(ec):
+    """int ÷ 0 -> ±inf, 0 ÷ 0 -> the x86 default NaN 0xFFF8…, operand NaNs propagate lhs-first, quieted."""
+    a = ec.CellBuffer.from_vec(np.array([0, 1, 7, 0], np.int8)) / ec.CellBuffer.from_vec(np.array([0, 0, 0, 5], np.uint16))
+    assert bits_of(a.to_numpy()).tolist() == [0xFFF8000000000000, 0x7FF0000000000000, 0x7FF0000000000000, 0]
+    a = ec.CellBuffer.from_vec(np.array([-3], np.int32)) / ec.CellBuffer.from_vec(np.array([0], np.uint8))
+    assert bits_of(a.to_numpy()).tolist() == [0xFFF0000000000000]
+    snan = np.array([0x7FF0000000000001, 0xFFF4000000000002], np.uint64).view(np.float64)
+    one = np.ones(2)
+    for op in OPS:
+        got = ec.CellBuffer.from_vec(snan)._binop(op, ec.CellBuffer.from_vec(one)).to_numpy()
+        assert bits_of(got).tolist() == [0x7FF8000000000001, 0xFFFC000000000002]
+        got = ec.CellBuffer.from_vec(one)._binop(op, ec.CellBuffer.from_vec(snan)).to_numpy()
+        assert bits_of(got).tolist() == [0x7FF8000000000001, 0xFFFC000000000002]
+    inf = np.array([np.inf])
+    assert bits_of((ec.CellBuffer.from_vec(inf) - ec.CellBuffer.from_vec(inf)).to_numpy())[0] == 0xFFF8000000000000
+    assert bits_of((ec.CellBuffer.from_vec(inf) * ec.CellBuffer.from_vec(np.zeros(1))).to_numpy())[0] == 0xFFF8000000000000
+    # f32 NaN payloads widen like cvtss2sd (payload << 29, quieted)
+    f = np.array([0x7FC00001, 0xFF800001], np.uint32).view(np.float32)
+    got = (ec.CellBuffer.from_vec(f) + ec.CellBuffer.from_vec(np.zeros(2, np.uint8))).to_numpy()
+    assert_f64_bits_equal(got, eco.f_binop(eco.ADD, f, np.zeros(2, np.uint8)))
+
+
+# ---------------------------------------------------------------- scalar rhs: src/buffer.rs:346-352
+@pytest.mark.parametrize("lct", range(NT))
+def test_binop_scalar_bit_exact(ec, lct):
+    n = 5001
+    l = rand_cells(lct, n, 31)
+    dl = ec.CellBuffer.from_vec(l)
+    with np.errstate(all="ignore"):
+        lnan = np.isnan(l.astype(np.float64))
+    for sct in range(NT):
+        for sval in (rand_cells(sct, 3, 32, specials=False)[1], 0, 2):
+            s_o = eco.Value.of(sct, sval)
+            s_d = ec.CellValue(sct, sval)
+            for op in OPS:
+                got = dl._binop(op, s_d)
+                assert got.cell_type() == ec.Float64
+                assert_f64_bits_equal(got.to_numpy(), eco.f_binop_scalar(op, l, s_o))
+    nan_s = ec.CellValue(ec.Float64, np.array([0xFFF0000000000123], np.uint64).view(np.float64)[0])
+    got = (dl * nan_s).to_numpy()
+    exp = eco.f_binop_scalar(eco.MUL, l, eco.Value.from_bits(eco.F64, 0xFFF0000000000123))
+    assert_f64_bits_equal(got, exp, nan_by_class_where=lnan)
+    assert (dl.shard(0, 0) * 2.0).cell_type() == ec.UInt8
+
+
+# ---------------------------------------------------------------- neg: src/buffer.rs:360-365
+@pytest.mark.parametrize("ct", range(NT))
+def test_neg_bit_exact(ec, ct):
+    for n in (1, 15, 16, 17, 4099, 70001):
+        a = rand_cells(ct, n, 41)
+        got = -ec.CellBuffer.from_vec(a)
+        exp = eco.neg(a) if n < 5000 else eco.f_neg(a)
+        assert ec.NP_DTYPES[got.cell_type()] == exp.dtype
+        assert np.array_equal(bits_of(got.to_numpy()), bits_of(exp))
+    got = -(ec.CellBuffer.from_vec(rand_cells(ct, 100, 42)).shard(3, 50))  # unaligned window
+    assert np.array_equal(bits_of(got.to_numpy()), bits_of(eco.f_neg(rand_cells(ct, 100, 42)[3:53])))
+    assert (-ec.CellBuffer.empty(0, ct)).cell_type() == ec.UInt8
+
+
+# ---------------------------------------------------------------- convert: src/buffer.rs:150-167
+@pytest.mark.parametrize("sct", range(NT))
+def test_convert_all_pairs(ec, sct):
+    n = 9001
+    a = rand_cells(sct, n, 51)
+    da = ec.CellBuffer.from_vec(a)
+    for dct in range(NT):
+        if eco.can_fit_into(sct, dct):
+            got = da.convert(dct)
+            assert got.cell_type() == dct and got.len() == n
+            assert np.array_equal(bits_of(got.to_numpy()), bits_of(eco.f_convert(a, dct)))
+            assert np.array_equal(bits_of(da.shard(1, 777).convert(dct).to_numpy()), bits_of(eco.convert(a[1:778], dct)))
+            assert np.array_equal(bits_of(da.to_vec(dct)), bits_of(eco.f_convert(a, dct)))
+        else:
+            with pytest.raises(ec.NarrowingError) as ei:
+                da.convert(dct)
+            assert (ei.value.src, ei.value.dst) == (sct, dct)
+            assert "Invalid narrowing from cell-type" in str(ei.value)
+    # empty convert to another type collects nothing -> UInt8 (buffer.rs:233-234)
+    if sct != eco.F64:
+        assert ec.CellBuffer.empty(0, sct).convert(eco.F64).cell_type() == ec.UInt8
+
+
+# ---------------------------------------------------------------- min_max: src/buffer.rs:169-173, masked_buffer.rs:208-217
+@pytest.mark.parametrize("ct", range(NT))
+def test_min_max_total_order(ec, ct):
+    for n in (0, 1, 5, 255, 4096, 100003, 1 << 21):
+        a = rand_cells(ct, n, 61)
+        d = ec.CellBuffer.from_vec(a)
+        for mask in (None, rand_mask(n, 62), np.zeros(n, np.uint8)):
+            if mask is None:
+                mn, mx = d.min_max()
+            else:
+                mn, mx = ec.MaskedCellBuffer(d, ec.Mask.new(mask)).min_max()
+            emn, emx = eco.f_min_max(a, mask)
+            assert (mn.ct, mn.bits(), mx.ct, mx.bits()) == (emn.ct, emn.bits(), emx.ct, emx.bits()), (n, mask is None)
+    a = rand_cells(ct, 5000, 63)
+    mn, mx = ec.CellBuffer.from_vec(a).shard(1, 4001).min_max()  # unaligned window
+    emn, emx = eco.min_max(a[1:4002])
+    assert (mn.bits(), mx.bits()) == (emn.bits(), emx.bits())
+
+
+# ---------------------------------------------------------------- masks: src/masked/*.rs
+@pytest.mark.parametrize("ct", range(NT))
+def test_mask_from_nodata_and_select(ec, ct):
+    n = 10007
+    a = rand_cells(ct, n, 71)
+    a[::7] = a[3]  # make the chosen nodata value frequent
+    d = ec.CellBuffer.from_vec(a)
+    for nd_o, nd_d in ((eco.nodata_value(eco.ND_DEFAULT, ct), ec.NoData.default()),
+                       (eco.Value.of(ct, a[3]), ec.NoData.new(ec.CellValue(ct, a[3]))),
+                       (None, ec.NoData.none())):
+        m = ec.mask_from_nodata(d, nd_d)
+        assert np.array_equal(m.to_numpy(), eco.f_mask_from_nodata(a, nd_o))
+        mk = rand_mask(n, 72)
+        got = ec.MaskedCellBuffer(d, ec.Mask.new(mk)).to_vec_with_nodata(ct, nd_d)
+        assert np.array_equal(bits_of(got), bits_of(eco.f_mask_select(a, mk, nd_o)))
+    sub = ec.mask_from_nodata(d.shard(5, 333), ec.NoData.default())
+    assert np.array_equal(sub.to_numpy(), eco.mask_from_nodata(a[5:338], eco.ND_DEFAULT))
+
+
+def test_float_nodata_is_bitwise(ec):
+    """Only the NaN with identical bits matches; -0.0 != +0.0 (nodata.rs:42-49 -> value.rs:248-271)."""
+    nan_c = np.array([0x7FF8000000000000], np.uint64).view(np.float64)[0]
+    v = np.array([1.0, nan_c, -nan_c, 0.0, -0.0])
+    v[2] = np.array([0xFFF8000000000000], np.uint64).view(np.float64)[0]
+    m = ec.MaskedCellBuffer.from_vec_with_nodata(v, ec.NoData.default()).mask().to_numpy()
+    assert m.tolist() == [1, 0, 1, 1, 1]
+    m = ec.MaskedCellBuffer.from_vec_with_nodata(v, ec.NoData.new(0.0)).mask().to_numpy()
+    assert m.tolist() == [1, 1, 1, 0, 1]
+
+
+def test_mask_logic_and_counts(ec):
+    for n in (0, 1, 15, 16, 17, 4095, 4097, 1 << 20, (1 << 22) + 3):
+        a, b = rand_mask(n, 81), rand_mask(n, 82, 0.4)
+        da, db = ec.Mask.new(a), ec.Mask.new(b)
+        assert np.array_equal((da & db).to_numpy(), eco.mask_and(a, b))
+        assert np.array_equal((da | db).to_numpy(), eco.mask_or(a, b))
+        assert np.array_equal((~da).to_numpy(), eco.mask_not(a))
+        assert da.counts() == eco.mask_counts(a)
+        assert da.all(True) == eco.mask_all(a, True) and da.all(False) == eco.mask_all(a, False)
+    a, b = rand_mask(1000, 83), rand_mask(600, 84)
+    assert (ec.Mask.new(a) & ec.Mask.new(b)).len() == 600  # borrowed forms zip (mask.rs:129-140)
+    m = ec.Mask.new(a)
+    m &= ec.Mask.new(b)                                     # owned form keeps lhs length (mask.rs:118-127)
+    assert m.len() == 1000
+    assert np.array_equal(m.to_numpy(), np.concatenate([a[:600] & b, a[600:]]))
+    assert ec.Mask.new(a).shard(7, 500).counts() == eco.mask_counts(a[7:507])  # unaligned window
+
+
+# ---------------------------------------------------------------- masked binop: src/masked/masked_buffer.rs:326-335
+@pytest.mark.parametrize("variant", [0, 1])
+def test_masked_binop_fused(ec, variant):
+    ec.lib().ec_tune_set(b"binop_variant", variant)
+    try:
+        for lct, rct in [(eco.F32, eco.F32), (eco.U8, eco.U16), (eco.F64, eco.F32), (eco.I64, eco.U8)]:
+            for n in (1, 17, 4096, 50001):
+                l, r = rand_cells(lct, n, 91), rand_cells(rct, n, 92)
+                lm, rm = rand_mask(n, 93), rand_mask(n, 94)
+                ml = ec.MaskedCellBuffer(ec.CellBuffer.from_vec(l), ec.Mask.new(lm))
+                mr = ec.MaskedCellBuffer(ec.CellBuffer.from_vec(r), ec.Mask.new(rm))
+                for op in OPS:
+                    got = ml._binop(op, mr)
+                    loose = _both_nan(l, r) if op in (eco.ADD, eco.MUL) else None
+                    # masked-out cells are still computed (masked_buffer.rs:331)
+                    assert_f64_bits_equal(got.buffer().to_numpy(), eco.f_binop(op, l, r), nan_by_class_where=loose)
+                    assert np.array_equal(got.mask().to_numpy(), eco.mask_and(lm, rm))
+        # unaligned windows -> cell-wise kernel
+        l, r = rand_cells(eco.F32, 3000, 95), rand_cells(eco.F32, 3000, 96)
+        lm, rm = rand_mask(3000, 97), rand_mask(3000, 98)
+        ml = ec.MaskedCellBuffer(ec.CellBuffer.from_vec(l), ec.Mask.new(lm)).shard(1, 2000)
+        mr = ec.MaskedCellBuffer(ec.CellBuffer.from_vec(r), ec.Mask.new(rm)).shard(3, 2000)
+        got = ml + mr
+        assert_f64_bits_equal(got.buffer().to_numpy(), eco.f_binop(eco.ADD, l[1:2001], r[3:2003]),
+                              nan_by_class_where=_both_nan(l[1:2001], r[3:2003]))
+        assert np.array_equal(got.mask().to_numpy(), lm[1:2001] & rm[3:2003])
+    finally:
+        ec.lib().ec_tune_set(b"binop_variant", 0)
+
+
+def test_synthetic_generators_match_oracle(ec):
+    """bench.py's device-side input generator == the oracle's."""
+    import ctypes as C
+    n = 100003
+    a = ec.CellBuffer.empty(n, ec.UInt8)
+    b = ec.CellBuffer.empty(n, ec.UInt16)
+    ec._ffi.check(ec.lib().ec_synth_fill(ec.UInt8, a.mem.ptr, n, 0x5EED0001, 5, 0.0, 255.0, None))
+    ec._ffi.check(ec.lib().ec_synth_fill(ec.UInt16, b.mem.ptr, n, 0x5EED0002, 5, 1.0, 65535.0, None))
+    assert np.array_equal(a.to_numpy(), eco.fill_u8(n, 0x5EED0001, base=5))
+    assert np.array_equal(b.to_numpy(), eco.fill_u16(n, 0x5EED0002, base=5, lo=1))
+    m = ec.Mask.empty(n)
+    ec._ffi.check(ec.lib().ec_synth_mask(m.mem.ptr, n, 0x5EED0013, 0, 30, None))
+    exp = np.array([eco.splitmix64(0x5EED0013 ^ i) % 100 >= 30 for i in range(2000)], np.uint8)
+    assert np.array_equal(m.to_numpy()[:2000], exp)
+    t, f = m.counts()
+    assert abs(f / n - 0.30) < 0.01

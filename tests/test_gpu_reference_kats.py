@@ -1,0 +1,313 @@
+"""The reference's own unit tests, doc-tests and examples,
+restated against the HIP path through the host mirror.  Each test names the
+reference test it mirrors; the same known answers pin the oracle in
+tests/test_oracle_kat.py, so HIP == oracle == reference KATs.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tiff_util import read_tiff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ec():
+    import erased_cells_hip as ec
+    ec.init(0)
+    return ec
+
+
+def test_quick_example(ec):
+    """examples/quick.rs:5-11"""
+    buf1 = ec.CellBuffer.from_vec(np.array([1, 2, 3], np.uint8))
+    buf2 = ec.CellBuffer.from_vec(np.array([2, 4, 6], np.uint16))
+    result = buf1 / buf2 * 0.5
+    assert result == ec.CellBuffer.from_vec([0.25, 0.25, 0.25])
+    assert result.cell_type() == ec.Float64
+
+
+def test_buffer_example(ec):
+    """examples/buffer.rs:5-30 and the doc-test at src/buffer.rs:20-49"""
+    buf1 = ec.CellBuffer.fill_via(9, lambda i: i, np.uint8)
+    assert buf1.cell_type() == ec.UInt8
+    assert buf1.get(3) == ec.CellValue(ec.UInt8, 3)
+    mn, mx = buf1.min_max()
+    assert (mn, mx) == (ec.CellValue(ec.UInt8, 0), ec.CellValue(ec.UInt8, 8))
+    assert (mn.ct, mx.ct) == (ec.UInt8, ec.UInt8)
+    buf2 = ec.CellBuffer.fill_via(9, lambda i: 8.0 - i, np.float32)
+    assert buf2.cell_type() == ec.Float32
+    assert buf2.min_max() == (ec.CellValue(ec.Float32, 0.0), ec.CellValue(ec.Float32, 8.0))
+    diff = buf2 - buf1
+    assert diff.min_max() == (ec.CellValue.new(-8), ec.CellValue.new(8))
+
+
+def test_buffer_defaults_put_get(ec):
+    """src/buffer.rs:462-487 (defaults, put_get)"""
+    for ct in ec.CELL_TYPES:
+        cv = ec.CellBuffer.with_defaults(3, ct)
+        assert cv.len() == 3 and cv.cell_type() == ct
+        assert cv.get(0) == ec.CellValue(ct, 0)
+        cv = ec.CellBuffer.fill(3, ec.CellValue(ct, 0))
+        one = ec.CellValue(ct, 1)
+        cv.put(1, one)
+        assert cv.get(1) == one.convert(ct)
+    with pytest.raises(ec.NarrowingError):
+        ec.CellBuffer.with_defaults(3, ec.UInt8).put(0, ec.CellValue(ec.Float32, 1.5))
+    with pytest.raises(IndexError):
+        ec.CellBuffer.with_defaults(3, ec.UInt8).get(3)
+
+
+def test_buffer_to_vec(ec):
+    """src/buffer.rs:501-513"""
+    for ct in ec.CELL_TYPES:
+        v = np.zeros(3, ec.NP_DTYPES[ct])
+        assert np.array_equal(ec.CellBuffer.from_vec(v).to_vec(ct), v)
+
+
+def test_buffer_min_max(ec):
+    """src/buffer.rs:516-526"""
+    mn, mx = ec.CellBuffer.from_vec([-1.0, 3.0, 2000.0, -5555.5]).min_max()
+    assert (mn, mx) == (ec.CellValue(ec.Float64, -5555.5), ec.CellValue(ec.Float64, 2000.0))
+    mn, mx = ec.CellBuffer.from_vec(np.array([1, 3, 200, 0], np.uint8)).min_max()
+    assert (mn.ct, mn.value, mx.ct, mx.value) == (ec.UInt8, 0, ec.UInt8, 200)
+
+
+def test_buffer_convert(ec):
+    """src/buffer.rs:567-578"""
+    for ct in ec.CELL_TYPES:
+        buf = ec.CellBuffer.with_defaults(3, ct)
+        for target in (t for t in ec.CELL_TYPES if ec.can_fit_into(ct, t)):
+            r = buf.convert(target)
+            assert r.cell_type() == target
+
+
+def test_buffer_unary(ec):
+    """src/buffer.rs:581-592 with the result types of src/value.rs:338-346"""
+    exp = {ec.UInt8: ec.Int16, ec.UInt16: ec.Int32, ec.UInt32: ec.Float64, ec.UInt64: ec.Float64}
+    for ct in ec.CELL_TYPES:
+        buf = -ec.CellBuffer.fill(3, ec.CellValue(ct, 1))
+        assert buf.cell_type() == exp.get(ct, ct)
+        assert buf.get(0) == ec.CellValue.new(-1)
+
+
+def test_buffer_binary(ec):
+    """src/buffer.rs:595-614: all 100 type pairs, four ops, both orders"""
+    pyop = [lambda a, b: a + b, lambda a, b: a - b, lambda a, b: a * b, lambda a, b: a / b]
+    for lhs_ct in ec.CELL_TYPES:
+        for rhs_ct in ec.CELL_TYPES:
+            lhs = ec.CellBuffer.fill(3, ec.CellValue(lhs_ct, 1))
+            rhs = ec.CellBuffer.fill(3, ec.CellValue(rhs_ct, 2))
+            for op in range(4):
+                r = lhs._binop(op, rhs)
+                assert r.cell_type() == ec.Float64
+                assert r.to_numpy().tolist() == [pyop[op](1.0, 2.0)] * 3
+                assert rhs._binop(op, lhs).to_numpy().tolist() == [pyop[op](2.0, 1.0)] * 3
+
+
+def test_buffer_scalar(ec):
+    """src/buffer.rs:617-621"""
+    buf = ec.CellBuffer.fill_via(9, lambda i: i + 1, np.uint8)
+    r = buf * 2.0
+    assert r == ec.CellBuffer.fill_via(9, lambda i: (i + 1.0) * 2.0, np.float64)
+
+
+def test_buffer_equal_cmp(ec):
+    """src/buffer.rs:624-672"""
+    buf = ec.CellBuffer.fill_via(9, lambda i: math.nan if i % 2 == 0 else float(i), np.float64)
+    assert buf == buf
+    wd = ec.CellBuffer.with_defaults
+    assert wd(4, ec.UInt8) == wd(4, ec.UInt8)
+    assert wd(4, ec.UInt8) != wd(5, ec.UInt8)
+    assert ec.CellBuffer.from_vec([1, 2, 3]) < ec.CellBuffer.from_vec([2, 3, 4])
+    assert ec.CellBuffer.from_vec([1, 2, 3]) < ec.CellBuffer.from_vec([2, 3])
+    assert ec.CellBuffer.from_vec([math.nan, 2.0, 3.0]) < ec.CellBuffer.from_vec([math.nan, 2.0, 4.0])
+    assert wd(4, ec.UInt8) < wd(4, ec.Float32) and wd(4, ec.Float32) > wd(4, ec.UInt8)
+    assert wd(4, ec.UInt8) < wd(5, ec.UInt8) and wd(5, ec.UInt8) > wd(4, ec.UInt8)
+    assert wd(4, ec.Float64) < wd(5, ec.Float64) and wd(5, ec.Float64) > wd(4, ec.Float64)
+
+
+def test_mask_tests(ec):
+    """src/masked/mask.rs:184-242 (counts, set, not, all, and, or)"""
+    assert ec.Mask.fill(3, True).counts() == (3, 0)
+    assert ec.Mask.fill(3, False).counts() == (0, 3)
+    assert ec.Mask.fill_via(3, lambda i: i % 2 == 0).counts() == (2, 1)
+    m = ec.Mask.fill(3, True)
+    m.put(1, False)
+    m.put(0, False)
+    assert m == ec.Mask.new([False, False, True])
+    t, f = ec.Mask.fill(4, True), ec.Mask.fill(4, False)
+    assert ~t == f
+    m, r = ec.Mask.new([True, False, True, False]), ec.Mask.new([False, True, False, True])
+    assert ~m == r
+    m = ec.Mask.fill_via(4, lambda i: i % 2 == 0)
+    assert not m.all(True) and not m.all(False)
+    assert ec.Mask.fill(4, True).all(True) and not ec.Mask.fill(4, True).all(False)
+    l, r = ec.Mask.fill_via(4, lambda i: i % 2 == 0), ec.Mask.fill_via(4, lambda i: i % 2 != 0)
+    assert (l & r).all(False) and (l | r).all(True)
+
+
+def test_nodata_tests(ec):
+    """src/masked/nodata.rs:75-95"""
+    assert ec.NoData.none().value(ec.Int16) is None
+    assert ec.NoData.default().value(ec.UInt8).value == 0
+    assert math.isnan(ec.NoData.default().value(ec.Float32).value)
+    assert ec.NoData.new(np.uint16(6)).value(ec.UInt16).value == 6
+    for ct in ec.CELL_TYPES:
+        assert ec.NoData.default().value(ct) is not None
+    m = ec.MaskedCellBuffer.from_vec_with_nodata([math.nan], ec.NoData.default())
+    assert m.mask().to_numpy().tolist() == [0]
+
+
+def test_masked_ctor_and_vec_with_nodata(ec):
+    """src/masked/masked_buffer.rs:400-425"""
+    m = ec.MaskedCellBuffer.fill_via(3, lambda i: i, np.uint8)
+    r = ec.MaskedCellBuffer.new(ec.CellBuffer.fill_via(3, lambda i: i, np.uint8), ec.Mask.fill(3, True))
+    assert m == r
+    assert ec.MaskedCellBuffer.from_vec([0.0] * 4).mask().counts() == (4, 0)
+    assert ec.MaskedCellBuffer.with_defaults(4, ec.Int16).mask().counts() == (4, 0)
+    v = [1.0, math.nan, 3.0, math.nan]
+    m = ec.MaskedCellBuffer.from_vec_with_nodata(v, ec.NoData.default())
+    assert m == ec.MaskedCellBuffer.new(ec.CellBuffer.from_vec(v), ec.Mask.new([True, False, True, False]))
+    m = ec.MaskedCellBuffer.from_vec_with_nodata(v, ec.NoData.new(3.0))
+    assert m == ec.MaskedCellBuffer.new(ec.CellBuffer.from_vec(v), ec.Mask.new([True, True, False, True]))
+    with pytest.raises(AssertionError):
+        ec.MaskedCellBuffer.new(ec.CellBuffer.from_vec(v), ec.Mask.fill(3, True))
+
+
+def _filler_masker(i):
+    return (i, i % 2 == 0)
+
+
+def test_masked_get_masked_convert(ec):
+    """src/masked/masked_buffer.rs:428-447"""
+    buf = ec.MaskedCellBuffer.fill_with_mask_via(9, _filler_masker, np.uint8)
+    assert buf.get(4) == ec.CellValue.new(4)
+    assert buf.get_masked(4) == ec.CellValue.new(4)
+    assert buf.get_masked(5) is None
+    buf.put(5, ec.CellValue(ec.UInt8, 4))
+    assert buf.get_masked(5) is None
+    buf.mask().put(5, True)
+    assert buf.get_masked(5) == ec.CellValue.new(4)
+    buf.put_with_mask(5, ec.CellValue(ec.UInt8, 99), False)
+    assert buf.get_masked(5) is None
+    buf = ec.MaskedCellBuffer.fill_with_mask_via(4, _filler_masker, np.uint8)
+    assert buf.convert(ec.Float64).to_vec(ec.Float64).tolist() == [0.0, 1.0, 2.0, 3.0]
+
+
+def test_masked_unary(ec):
+    """src/masked/masked_buffer.rs:465-479"""
+    mbuf = ec.MaskedCellBuffer.fill_with_mask_via(9, _filler_masker, np.uint8)
+    r = -mbuf
+    v = r.to_vec_with_nodata(ec.Int16, ec.NoData.default())
+    m = -32768
+    assert v.dtype == np.int16 and v.tolist() == [0, m, -2, m, -4, m, -6, m, -8]
+
+
+def test_masked_min_max_and_scalar(ec):
+    """src/masked/masked_buffer.rs:482-509"""
+    mbuf = ec.MaskedCellBuffer.fill_with_mask_via(9, lambda i: (i, i != 0 and i != 8), np.uint8)
+    assert mbuf.min_max() == (ec.CellValue(ec.UInt8, 1), ec.CellValue(ec.UInt8, 7))
+    mbuf = ec.MaskedCellBuffer.fill_with_mask_via(9, lambda i: (i, True), np.uint8)
+    r = mbuf * 2.0
+    expected = ec.CellBuffer.fill_via(9, lambda i: i, np.uint8) * 2.0
+    assert r == ec.MaskedCellBuffer.from_buffer(expected)
+    mbuf = ec.MaskedCellBuffer.fill_with_mask_via(9, _filler_masker, np.uint8)
+    r = mbuf * 2.0
+    assert r != ec.MaskedCellBuffer.from_buffer(expected)
+    fmin = np.finfo(np.float64).min
+    v = r.to_vec_with_nodata(ec.Float64, ec.NoData.new(fmin))
+    assert v.tolist() == [0.0, fmin, 4.0, fmin, 8.0, fmin, 12.0, fmin, 16.0]
+
+
+def test_masked_binary(ec):
+    """src/masked/masked_buffer.rs:512-531"""
+    lhs = ec.MaskedCellBuffer.new(ec.CellBuffer.fill(9, 1.0), ec.Mask.fill_via(9, lambda i: i % 2 == 0))
+    rhs = ec.MaskedCellBuffer.new(ec.CellBuffer.fill(9, 2.0), ec.Mask.fill(9, True))
+    pyop = [lambda a, b: a + b, lambda a, b: a - b, lambda a, b: a * b, lambda a, b: a / b]
+    for op in range(4):
+        r = lhs._binop(op, rhs)
+        assert r.get_masked(0) == ec.CellValue.new(pyop[op](1.0, 2.0))
+        assert r.get_masked(1) is None
+        assert r.get_masked(4) == ec.CellValue.new(pyop[op](1.0, 2.0))
+        assert r.get_masked(5) is None
+
+
+def test_masked_example(ec):
+    """examples/masked.rs:5-23 and the doc-test at src/masked/masked_buffer.rs:15-38"""
+    buf = ec.MaskedCellBuffer.fill_with_mask_via(4, lambda i: (float(i), i % 2 == 0), np.float64)
+    assert buf.mask() == ec.Mask.new([True, False, True, False])
+    assert buf.counts() == (2, 2)
+    ones = ec.MaskedCellBuffer.from_vec([1.0] * 4)
+    r = (buf + ones) * 2.0
+    expected = ec.MaskedCellBuffer.new(ec.CellBuffer.from_vec([2.0, 4.0, 6.0, 8.0]), ec.Mask.new([True, False, True, False]))
+    assert r == expected
+
+
+# ---- GDAL tests on the Landsat fixtures: src/gdal/rasterband.rs:138-191, doc-tests :20-36, :57-71
+NDVI_MIN_HEX, NDVI_MAX_HEX = "-0x1.ff8ca5bcc77dcp-4", "0x1.5708125b0ed28p-1"
+
+
+def _band(golden_dir, name):
+    cells, nd = read_tiff(os.path.join(golden_dir, f"L8-Elkton-VA-{name}.tiff"))
+    return cells, nd
+
+
+def test_read_cells_min_max_doc_test(ec, golden_dir):
+    """src/gdal/rasterband.rs:27-33: buffer.min_max() equals the band's min/max (B.24)"""
+    for name, lo, hi in (("B5", 5469, 39368), ("B4", 6396, 27835), ("B5-nd", 0, 39368)):
+        cells, _ = _band(golden_dir, name)
+        mn, mx = ec.CellBuffer.from_vec(cells.ravel()).min_max()
+        assert (mn.ct, mn.value, mx.value) == (ec.UInt16, lo, hi)
+
+
+def test_read_cells_ndvi(ec, golden_dir):
+    """src/gdal/rasterband.rs:138-163 (B.25)"""
+    red = ec.CellBuffer.from_vec(_band(golden_dir, "B4")[0].ravel())
+    nir = ec.CellBuffer.from_vec(_band(golden_dir, "B5")[0].ravel())
+    ndvi = (nir - red) / (nir + red)
+    mn, mx = ndvi.min_max()
+    assert mn.to_f64() - -0.1248899911993 < 1e-8 and mx.to_f64() - 0.66998345719859 < 1e-8
+    assert float(mn.value).hex() == NDVI_MIN_HEX and float(mx.value).hex() == NDVI_MAX_HEX
+
+
+def test_read_cells_masked_ndvi_sharded(ec, golden_dir):
+    """src/gdal/rasterband.rs:166-191 (B.26, B.27) — and BASELINE config 5: convert u16->f32,
+    NDVI, rows sharded 8 ways (22,21,...,21), shard results combined through the min/max keys."""
+    from erased_cells_hip import sharded
+    red_c, red_nd = _band(golden_dir, "B4")
+    nir_c, nir_nd = _band(golden_dir, "B5-nd")
+    rows, cols = red_c.shape
+    red = ec.MaskedCellBuffer.from_vec_with_nodata(red_c.ravel(), ec.NoData.new(np.uint16(red_nd)))
+    nir = ec.MaskedCellBuffer.from_vec_with_nodata(nir_c.ravel(), ec.NoData.new(np.uint16(nir_nd)))
+    nir_data, nir_nodata = nir.counts()
+    assert (nir_data, nir_nodata) == (31430, 4) and nir_data + nir_nodata == 186 * 169
+    ndvi = (nir - red) / (nir + red)
+    assert ndvi.counts() == (nir_data, nir_nodata)
+    mn, mx = ndvi.min_max()
+    assert float(mn.value).hex() == NDVI_MIN_HEX and float(mx.value).hex() == NDVI_MAX_HEX
+    # 8 row-block shards on one GPU
+    import ctypes as C
+    key_lo, key_hi, data, nodata, lens = None, None, 0, 0, []
+    for g in range(8):
+        off, ln = sharded.shard_range(rows, cols, g, 8)
+        lens.append(ln // cols)
+        r32 = red.shard(off, ln).convert(ec.Float32)
+        n32 = nir.shard(off, ln).convert(ec.Float32)
+        part = (n32 - r32) / (n32 + r32)
+        d, nd = part.counts()
+        data, nodata = data + d, nodata + nd
+        keys = ec.DeviceMem(16)
+        ec._ffi.check(ec.lib().ec_min_max_keys(part.cell_type(), part.buffer().mem.ptr, part.mask().mem.ptr, part.len(),
+                                               keys.ptr, None))
+        k = np.empty(2, np.int64)
+        ec._ffi.check(ec.lib().ec_download(k.ctypes.data_as(C.c_void_p), keys.ptr, 16, None))
+        key_lo = int(k[0]) if key_lo is None else max(key_lo, int(k[0]))
+        key_hi = int(k[1]) if key_hi is None else max(key_hi, int(k[1]))
+    assert lens == [22, 21, 21, 21, 21, 21, 21, 21]
+    assert (data, nodata) == (31430, 4)
+    smn, smx = sharded.combine_min_max_keys(ec.Float64, (key_lo, key_hi))
+    assert float(smn.value).hex() == NDVI_MIN_HEX and float(smx.value).hex() == NDVI_MAX_HEX
