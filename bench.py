@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the erased-cells MI355X path.
+
+Workload (BASELINE.json configs[1]): 16384 x 16384 u8 ÷ u16 -> f64 `CellBuffer`
+divide (src/buffer.rs:324-329 of the reference), inputs resident in HBM, one
+"step" = one pass of the divide over the whole raster.  With --gpus N the raster
+is cut into N contiguous row-blocks (one process / GPU); the divide
+needs no data-path collective.  Scaling is therefore "strong": the raster is
+fixed at 16384² (north_star) and each rank owns rows/N of it.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line: BASELINE.json's metric (Gcells/s, whole job), a
+`roofline` object for the dominant kernel (HIP-event timed, algorithmic bytes =
+11 B/cell) and, at N=1, a `cpu_baseline` object: the oracle's reference-shaped
+port of the same operation timed on this box's host cores on a bounded sample.
+
+Other workloads (not bench lines; used for profiles/ and DESIGN.md):
+  --workload masked_chain   config 3: f32 (a+b)*c with 30 % nodata masks
+  --workload minmax         config 4 per-GPU shard: u16 min_max (+ all-reduce of the keys)
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "erased-cells_amd", "python"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
+METRIC = "Gcells/s + HBM-GB/s roofline %, u8/u16->f64 16384^2, 1/2/4/8 GPUs"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--side", type=int, default=16384, help="raster is side x side cells")
+    ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: one side² raster row-sharded over the ranks (default); weak: side² per rank")
+    ap.add_argument("--variant", type=int, default=None, help="binop kernel variant: 0 direct, 1 LDS-staged")
+    ap.add_argument("--bpc", type=int, default=None, help="blocks-per-CU cap (0 = one block per tile)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(side: int, target_s: float) -> dict:
+    """The oracle (test infrastructure) as the reported CPU baseline: the reference-shaped port of
+    src/buffer.rs:327 + src/value.rs:199-217 + src/buffer.rs:229-250, single thread like the reference."""
+    import numpy as np
+    from oracle import eco
+
+    probe = 1 << 20
+    a, b = eco.fill_u8(probe, 0x5EED0001), eco.fill_u16(probe, 0x5EED0002, lo=1)
+    eco.binop(eco.DIV, a, b)  # warm
+    t = time.perf_counter()
+    eco.binop(eco.DIV, a, b)
+    rate = probe / (time.perf_counter() - t)
+    rows = max(8, min(side, int(rate * target_s) // side))
+    n = rows * side
+    a, b = eco.fill_u8(n, 0x5EED0001), eco.fill_u16(n, 0x5EED0002, lo=1)
+    t = time.perf_counter()
+    out = eco.binop(eco.DIV, a, b)
+    dt = time.perf_counter() - t
+    res = {"value": n / dt / 1e9, "unit": "Gcells/s", "cores": 1, "kind": "port",
+           "sample": f"first {rows} rows x {side} cols of the same raster ({n} cells, {dt:.1f} s), "
+                     f"reference-shaped oracle (16-byte tagged cells, per-cell union/convert, two-pass collect)"}
+    # next to it: the typed-loop form on all host cores ("optimised CPU")
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 64)
+    eco.set_threads(cores)
+    o2 = np.empty(n, dtype=np.float64)
+    eco.f_binop(eco.DIV, a, b, o2)
+    t = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        eco.f_binop(eco.DIV, a, b, o2)
+    dt2 = (time.perf_counter() - t) / reps
+    eco.set_threads(0)
+    res["typed_loop_all_cores"] = {"value": n / dt2 / 1e9, "unit": "Gcells/s", "cores": cores}
+    assert np.array_equal(out, o2)
+    return res
+
+
+def recorded_traffic(cells_per_launch: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/traffic.json, corrected as MI355X_MICROARCH.md §HBM prescribes); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            rec = json.load(f)
+        e = rec.get("binop_div_u8_u16", {})
+        if e.get("cells_per_launch") == cells_per_launch:
+            return e.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import erased_cells_hip as ec
+    from erased_cells_hip import sharded
+
+    ec.init(local_rank)
+    L = ec.lib()
+    if args.variant is not None:
+        ec._ffi.check(L.ec_tune_set(b"binop_variant", args.variant))
+    if args.bpc is not None:
+        ec._ffi.check(L.ec_tune_set(b"bpc", args.bpc))
+    stream = torch.cuda.current_stream().cuda_stream
+    ec.set_stream(stream)
+
+    side = args.side
+    rows_total = side * (world if args.scaling == "weak" else 1)
+    off, n = sharded.shard_range(rows_total, side, rank, world)
+    total_cells = rows_total * side
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- inputs, generated on the device, resident in HBM before timing
+    chk = ec._ffi.check
+    if args.workload == "div_u8_u16":
+        a, b = ec.CellBuffer.empty(n, ec.UInt8), ec.CellBuffer.empty(n, ec.UInt16)
+        out = ec.CellBuffer.empty(n, ec.Float64)
+        chk(L.ec_synth_fill(ec.UInt8, a.mem.ptr, n, 0x5EED0001, off, 0.0, 255.0, stream))
+        chk(L.ec_synth_fill(ec.UInt16, b.mem.ptr, n, 0x5EED0002, off, 1.0, 65535.0, stream))
+        bytes_per_cell, kernel = 11, "k_binop_direct<u8,u16,Div>" if (args.variant or 0) == 0 else "k_binop_lds<u8,u16,Div>"
+        wl = f"{side}x{side} u8/u16->f64 CellBuffer divide (BASELINE configs[1])"
+
+        def step():
+            chk(L.ec_binop(ec.DIV, ec.UInt8, a.mem.ptr, ec.UInt16, b.mem.ptr, n, out.mem.ptr, stream))
+    elif args.workload == "masked_chain":
+        bufs = [ec.CellBuffer.empty(n, ec.Float32) for _ in range(3)]
+        masks = [ec.Mask.empty(n) for _ in range(3)]
+        for i, (bf, mk) in enumerate(zip(bufs, masks)):
+            chk(L.ec_synth_fill(ec.Float32, bf.mem.ptr, n, 0x5EED0003 + i, off, -1000.0, 1000.0, stream))
+            chk(L.ec_synth_mask(mk.mem.ptr, n, 0x5EED0013 + i, off, 30, stream))
+        t1, m1 = ec.CellBuffer.empty(n, ec.Float64), ec.Mask.empty(n)
+        out, m2 = ec.CellBuffer.empty(n, ec.Float64), ec.Mask.empty(n)
+        bytes_per_cell, kernel = 42, "k_masked_binop<f32,f32,Add> + k_masked_binop<f64,f32,Mul>"
+        wl = f"{side}x{side} MaskedCellBuffer f32 (a+b)*c, 30% nodata (BASELINE configs[2], eager)"
+
+        def step():
+            chk(L.ec_masked_binop(ec.ADD, ec.Float32, bufs[0].mem.ptr, masks[0].mem.ptr, ec.Float32, bufs[1].mem.ptr,
+                                  masks[1].mem.ptr, n, t1.mem.ptr, m1.mem.ptr, stream))
+            chk(L.ec_masked_binop(ec.MUL, ec.Float64, t1.mem.ptr, m1.mem.ptr, ec.Float32, bufs[2].mem.ptr,
+                                  masks[2].mem.ptr, n, out.mem.ptr, m2.mem.ptr, stream))
+    else:
+        a = ec.CellBuffer.empty(n, ec.UInt16)
+        chk(L.ec_synth_fill(ec.UInt16, a.mem.ptr, n, 0x5EED0006, off, 1.0, 65534.0, stream))
+        keys = torch.empty(2, dtype=torch.int64, device="cuda")
+        bytes_per_cell, kernel = 2, "k_min_max_partials<u16>"
+        wl = f"{side}x{side} u16 min_max, row-sharded, all-reduce of 2 int64 keys (BASELINE configs[3] shape)"
+
+        def step():
+            chk(L.ec_min_max_keys(ec.UInt16, a.mem.ptr, None, n, keys.data_ptr(), stream))
+            if world > 1:
+                dist.all_reduce(keys, op=dist.ReduceOp.MAX)
+
+    # ---- warm-up, then EXACTLY `steps` timed steps between barrier+synchronize
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream
+
+    tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, dev_ms = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        launch_ms = dev_ms / args.steps
+        achieved = bytes_per_cell * n / (launch_ms * 1e-3) / 1e9
+        res = {
+            "metric": METRIC if args.workload == "div_u8_u16" else f"Gcells/s ({args.workload})",
+            "value": total_cells / (elapsed / args.steps) / 1e9,
+            "unit": "Gcells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": "f64" if args.workload != "minmax" else "u16",
+            "data": "synthetic",
+            "config": {"workload": wl, "rows": rows_total, "cols": side, "cells": total_cells,
+                       "cells_per_gpu": n, "sharding": "contiguous row-block per rank, no data-path collective",
+                       "inputs": "splitmix64 counter streams generated on device, resident in HBM",
+                       "kernel_variant": "lds" if (args.variant or 0) == 1 else "direct"},
+            "roofline": {"bound": "hbm", "kernel": kernel,
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": recorded_traffic(n) if (args.workload == "div_u8_u16" and world == 1) else None,
+                         "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": n,
+                         "launch_ms": launch_ms, "timer": "hipEvent pair on the launch stream over the timed region / steps"},
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "div_u8_u16":
+            res["cpu_baseline"] = cpu_baseline(side, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
