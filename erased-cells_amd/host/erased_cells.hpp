@@ -1,0 +1,594 @@
+// erased_cells.hpp — C++ host mirror of the `erased-cells` API over the C ABI.
+//
+// The reference is a Rust crate; this image has no Rust toolchain, so the
+// compiled host side above include/erased_cells.h is this header (C++17,
+// header-only, links only liberased_cells_hip.so).  It keeps the reference's
+// names, argument meaning and error behaviour:
+//
+//   CellType / CellEncoding / with_ct!   src/ctype.rs, src/encoding.rs, src/lib.rs:85-101
+//   CellValue                            src/value.rs
+//   CellBuffer + BufferOps + std::ops    src/buffer.rs, src/lib.rs:104-163
+//   Mask / MaskedCellBuffer / NoData<T>  src/masked/*.rs
+//   Error::NarrowingError                src/error.rs:14-15  (thrown as NarrowingError)
+//
+// What stays on the host — exactly what the reference's host code decides once
+// per operation: the dtype-erased dispatch tag, zip truncation (buffer.rs:327),
+// "empty result is UInt8" (buffer.rs:233-234), length asserts (panics become
+// std::logic_error).  Every per-cell loop body is one call into the HIP library;
+// buffers stay resident in HBM between operations (from_vec uploads once,
+// to_vec downloads).  Scalar CellValue arithmetic is host arithmetic in the
+// reference too (one f64 op) and stays so here.
+//
+// Rust ownership maps to C++ as: `&CellBuffer` -> const CellBuffer&, owned ->
+// by value / rvalue; Clone is explicit (`clone()`), copies are deleted.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "erased_cells.h"
+
+namespace erased_cells {
+
+// ---------------------------------------------------------------- CellType (src/ctype.rs:11-20)
+enum class CellType : uint8_t { UInt8, UInt16, UInt32, UInt64, Int8, Int16, Int32, Int64, Float32, Float64 };
+
+// with_ct! (src/lib.rs:85-101): X(Variant, primitive)
+#define EC_HOST_WITH_CT(X) \
+    X(UInt8, uint8_t) X(UInt16, uint16_t) X(UInt32, uint32_t) X(UInt64, uint64_t) X(Int8, int8_t) \
+    X(Int16, int16_t) X(Int32, int32_t) X(Int64, int64_t) X(Float32, float) X(Float64, double)
+
+inline const char* to_string(CellType ct) {
+    static const char* n[] = {"UInt8", "UInt16", "UInt32", "UInt64", "Int8", "Int16", "Int32", "Int64", "Float32", "Float64"};
+    return n[static_cast<int>(ct)];
+}
+inline std::vector<CellType> cell_types() {  // CellType::iter (ctype.rs:47-52)
+    std::vector<CellType> v;
+    for (int i = 0; i < EC_NTYPES; ++i) v.push_back(static_cast<CellType>(i));
+    return v;
+}
+
+// ---------------------------------------------------------------- errors (src/error.rs)
+struct Error : std::runtime_error {
+    ec_status status;
+    Error(ec_status s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+struct NarrowingError : Error {  // Error::NarrowingError{src,dst}
+    CellType src, dst;
+    NarrowingError(CellType s, CellType d)
+        : Error(EC_ERR_NARROWING, std::string("Invalid narrowing from cell-type ") + to_string(s) + " to " + to_string(d)),
+          src(s), dst(d) {}
+};
+struct ParseError : Error {  // Error::ParseError (ctype.rs:37)
+    explicit ParseError(const std::string& s) : Error(EC_ERR_ARG, "Unable to parse " + s + " as a CellType") {}
+};
+
+inline void check(ec_status st) {
+    if (st == EC_OK) return;
+    if (st == EC_ERR_NARROWING) {
+        ec_dtype s = 0, d = 0;
+        ec_last_narrowing(&s, &d);
+        throw NarrowingError(static_cast<CellType>(s), static_cast<CellType>(d));
+    }
+    throw Error(st, ec_last_error_string());
+}
+
+inline CellType cell_type_from_str(const std::string& s) {  // FromStr (ctype.rs:29-43)
+    for (CellType ct : cell_types())
+        if (s == to_string(ct)) return ct;
+    throw ParseError(s);
+}
+inline bool is_integral(CellType ct) { return ct != CellType::Float32 && ct != CellType::Float64; }
+inline bool is_signed(CellType ct) { return static_cast<int>(ct) >= EC_I8; }
+inline size_t size_of(CellType ct) { return ec_size_of(static_cast<ec_dtype>(ct)); }
+inline CellType union_of(CellType a, CellType b) {  // CellType::union (ctype.rs:99-126)
+    return static_cast<CellType>(ec_union(static_cast<ec_dtype>(a), static_cast<ec_dtype>(b)));
+}
+inline bool can_fit_into(CellType a, CellType b) {  // ctype.rs:129-131
+    return ec_can_fit_into(static_cast<ec_dtype>(a), static_cast<ec_dtype>(b)) != 0;
+}
+
+// ---------------------------------------------------------------- CellEncoding (src/encoding.rs:9-40)
+template <typename T> struct CellEncoding;
+#define EC_ENC(ID, P)                                             \
+    template <> struct CellEncoding<P> {                          \
+        static constexpr CellType cell_type() { return CellType::ID; } \
+    };
+EC_HOST_WITH_CT(EC_ENC)
+#undef EC_ENC
+
+// ---------------------------------------------------------------- CellValue (src/value.rs)
+class CellValue {
+    ec_value v_{};
+
+public:
+    CellValue() { v_.dtype = EC_U8; }
+    explicit CellValue(const ec_value& v) : v_(v) {}
+    template <typename T, typename = decltype(CellEncoding<T>::cell_type())>
+    CellValue(T x) {  // CellValue::new / From<T> (value.rs:24-33, :111-115)
+        std::memset(&v_, 0, sizeof v_);
+        v_.dtype = static_cast<uint8_t>(CellEncoding<T>::cell_type());
+        std::memcpy(&v_.v, &x, sizeof x);
+    }
+    const ec_value& raw() const { return v_; }
+    CellType cell_type() const { return static_cast<CellType>(v_.dtype); }
+
+    CellValue convert(CellType ct) const {  // value.rs:74-98
+        ec_value out;
+        check(ec_value_convert(&v_, static_cast<ec_dtype>(ct), &out));
+        return CellValue(out);
+    }
+    template <typename T> T get() const {  // value.rs:51-67
+        CellValue c = convert(CellEncoding<T>::cell_type());
+        T x;
+        std::memcpy(&x, &c.v_.v, sizeof x);
+        return x;
+    }
+    std::pair<CellValue, CellValue> unify(const CellValue& o) const {  // value.rs:103-107
+        CellType d = union_of(cell_type(), o.cell_type());
+        return {convert(d), o.convert(d)};
+    }
+    double to_f64() const { return ec_value_to_f64(&v_); }  // value.rs:145-156
+    uint64_t bits() const {
+        uint64_t b = 0;
+        std::memcpy(&b, &v_.v, size_of(cell_type()));
+        return b;
+    }
+    static CellValue zero() { return CellValue(uint8_t(0)); }  // value.rs:166-170
+    static CellValue one() { return CellValue(uint8_t(1)); }   // value.rs:159-164
+    bool is_zero() const { return to_f64() == 0.0; }
+
+    // impl Ord (value.rs:248-265): unify, ints natural, floats total_cmp
+    int cmp(const CellValue& o) const {
+        auto [l, r] = unify(o);
+        auto key = [](const CellValue& c) -> int64_t {  // order-preserving int64 key of a unified value
+            switch (c.cell_type()) {
+                case CellType::UInt64: return static_cast<int64_t>(c.get<uint64_t>() ^ 0x8000000000000000ull);
+                case CellType::Float32: {
+                    int32_t b; float f = c.get<float>(); std::memcpy(&b, &f, 4);
+                    return b ^ static_cast<int32_t>(static_cast<uint32_t>(b >> 31) >> 1);
+                }
+                case CellType::Float64: {
+                    int64_t b; double d = c.get<double>(); std::memcpy(&b, &d, 8);
+                    return b ^ static_cast<int64_t>(static_cast<uint64_t>(b >> 63) >> 1);
+                }
+                default: return is_signed(c.cell_type()) ? c.get<int64_t>() : static_cast<int64_t>(c.get<uint64_t>());
+            }
+        };
+        int64_t a = key(l), b = key(r);
+        return (a > b) - (a < b);
+    }
+    bool operator==(const CellValue& o) const { return cmp(o) == 0; }  // value.rs:267-271
+    bool operator!=(const CellValue& o) const { return cmp(o) != 0; }
+    bool operator<(const CellValue& o) const { return cmp(o) < 0; }
+    bool operator>(const CellValue& o) const { return cmp(o) > 0; }
+    CellValue min(const CellValue& o) const { return cmp(o) <= 0 ? *this : o; }
+    CellValue max(const CellValue& o) const { return cmp(o) > 0 ? *this : o; }
+};
+
+// cv_bin_op! (value.rs:199-217): unify, to_f64 both, op -> always Float64. One scalar f64 op on the host.
+#define EC_CV_OP(OPSYM)                                                   \
+    inline CellValue operator OPSYM(const CellValue& l, const CellValue& r) { \
+        auto [a, b] = l.unify(r);                                         \
+        return CellValue(a.to_f64() OPSYM b.to_f64());                    \
+    }
+EC_CV_OP(+) EC_CV_OP(-) EC_CV_OP(*) EC_CV_OP(/)
+#undef EC_CV_OP
+
+inline CellValue operator-(const CellValue& v) {  // impl Neg (value.rs:224-240)
+    switch (v.cell_type()) {
+        case CellType::UInt8: return CellValue(static_cast<int16_t>(-static_cast<int16_t>(v.get<uint8_t>())));
+        case CellType::UInt16: return CellValue(static_cast<int32_t>(-static_cast<int32_t>(v.get<uint16_t>())));
+        case CellType::UInt32: return CellValue(-static_cast<double>(v.get<uint32_t>()));
+        case CellType::UInt64: return CellValue(-static_cast<double>(v.get<uint64_t>()));
+        case CellType::Int8: return CellValue(static_cast<int8_t>(0u - static_cast<uint8_t>(v.get<int8_t>())));
+        case CellType::Int16: return CellValue(static_cast<int16_t>(0u - static_cast<uint16_t>(v.get<int16_t>())));
+        case CellType::Int32: return CellValue(static_cast<int32_t>(0u - static_cast<uint32_t>(v.get<int32_t>())));
+        case CellType::Int64: return CellValue(static_cast<int64_t>(0ull - static_cast<uint64_t>(v.get<int64_t>())));
+        case CellType::Float32: return CellValue(-v.get<float>());
+        default: return CellValue(-v.get<double>());
+    }
+}
+
+inline CellValue zero(CellType ct) {  // CellType::zero (ctype.rs:134-143)
+    switch (ct) {
+#define EC_Z(ID, P) case CellType::ID: return CellValue(P(0));
+        EC_HOST_WITH_CT(EC_Z)
+#undef EC_Z
+    }
+    return CellValue();
+}
+inline CellValue one(CellType ct) {  // CellType::one (ctype.rs:146-155)
+    switch (ct) {
+#define EC_O(ID, P) case CellType::ID: return CellValue(P(1));
+        EC_HOST_WITH_CT(EC_O)
+#undef EC_O
+    }
+    return CellValue();
+}
+inline CellValue min_value(CellType ct) { ec_value v; check(ec_min_value(static_cast<ec_dtype>(ct), &v)); return CellValue(v); }
+inline CellValue max_value(CellType ct) { ec_value v; check(ec_max_value(static_cast<ec_dtype>(ct), &v)); return CellValue(v); }
+
+// ---------------------------------------------------------------- device plumbing
+inline void init(int device = 0) { check(ec_init(device)); }
+
+class DeviceMem {  // one HBM allocation
+    void* p_ = nullptr;
+    size_t bytes_ = 0;
+
+public:
+    explicit DeviceMem(size_t bytes) : bytes_(bytes) { check(ec_alloc(&p_, bytes)); }
+    ~DeviceMem() { if (p_) ec_free(p_); }
+    DeviceMem(const DeviceMem&) = delete;
+    DeviceMem& operator=(const DeviceMem&) = delete;
+    void* ptr() const { return p_; }
+    size_t bytes() const { return bytes_; }
+};
+
+inline ec_stream& current_stream() { static thread_local ec_stream s = nullptr; return s; }
+
+// ---------------------------------------------------------------- NoData<T> (src/masked/nodata.rs)
+template <typename T>
+struct NoData {
+    enum Kind { NoneK, DefaultK, ValueK } kind = DefaultK;
+    T v{};
+    static NoData None() { return {NoneK, T{}}; }
+    static NoData Default() { return {DefaultK, T{}}; }
+    static NoData new_(T x) { return {ValueK, x}; }
+    std::optional<T> value() const {  // nodata.rs:23-40
+        if (kind == NoneK) return std::nullopt;
+        if (kind == ValueK) return v;
+        ec_value d;
+        check(ec_nodata_default(static_cast<ec_dtype>(CellEncoding<T>::cell_type()), &d));
+        T x;
+        std::memcpy(&x, &d.v, sizeof x);
+        return x;
+    }
+    bool is(const CellValue& value) const {  // nodata.rs:42-49
+        auto nd = this->value();
+        return nd ? CellValue(*nd) == value : false;
+    }
+};
+
+// ---------------------------------------------------------------- CellBuffer (src/buffer.rs)
+class CellBuffer {
+    CellType ct_ = CellType::UInt8;
+    size_t n_ = 0;
+    std::shared_ptr<DeviceMem> mem_;
+
+    static CellBuffer empty_u8() { return CellBuffer(CellType::UInt8, 0); }  // buffer.rs:233-234
+
+public:
+    CellBuffer() = default;
+    CellBuffer(CellType ct, size_t n) : ct_(ct), n_(n), mem_(std::make_shared<DeviceMem>(n * size_of(ct))) {}
+    CellBuffer(CellBuffer&&) = default;
+    CellBuffer& operator=(CellBuffer&&) = default;
+    CellBuffer(const CellBuffer&) = delete;  // Clone is explicit, as in Rust
+    CellBuffer& operator=(const CellBuffer&) = delete;
+
+    void* ptr() const { return mem_ ? mem_->ptr() : nullptr; }
+
+    // ---- BufferOps (src/lib.rs:104-163)
+    template <typename T> static CellBuffer from_vec(const std::vector<T>& data) {  // buffer.rs:64-66
+        CellBuffer b(CellEncoding<T>::cell_type(), data.size());
+        check(ec_upload(b.ptr(), data.data(), data.size() * sizeof(T), current_stream()));
+        return b;
+    }
+    template <typename T> static CellBuffer new_(const std::vector<T>& data) { return from_vec(data); }
+    static CellBuffer with_defaults(size_t len, CellType ct) { return fill(len, zero(ct)); }  // buffer.rs:68-77
+    static CellBuffer fill(size_t len, const CellValue& value) {                              // buffer.rs:79-88
+        CellBuffer b(value.cell_type(), len);
+        check(ec_fill(static_cast<ec_dtype>(value.cell_type()), b.ptr(), len, &value.raw(), current_stream()));
+        return b;
+    }
+    template <typename T, typename F> static CellBuffer fill_via(size_t len, F f) {            // buffer.rs:90-97
+        std::vector<T> v(len);
+        for (size_t i = 0; i < len; ++i) v[i] = f(i);
+        return from_vec(v);
+    }
+    size_t len() const { return n_; }
+    bool is_empty() const { return n_ == 0; }
+    CellType cell_type() const { return ct_; }
+    CellBuffer clone() const {
+        CellBuffer b(ct_, n_);
+        check(ec_copy(b.ptr(), ptr(), n_ * size_of(ct_), current_stream()));
+        return b;
+    }
+    CellValue get(size_t index) const {  // buffer.rs:125-134; panics on OOB
+        if (index >= n_) throw std::out_of_range("index out of bounds: the len is " + std::to_string(n_) + " but the index is " + std::to_string(index));
+        ec_value v;
+        std::memset(&v, 0, sizeof v);
+        v.dtype = static_cast<uint8_t>(ct_);
+        check(ec_download(&v.v, static_cast<const char*>(ptr()) + index * size_of(ct_), size_of(ct_), current_stream()));
+        return CellValue(v);
+    }
+    void put(size_t idx, const CellValue& value) {  // buffer.rs:136-148
+        CellValue c = value.convert(ct_);
+        if (idx >= n_) throw std::out_of_range("index out of bounds");
+        check(ec_upload(static_cast<char*>(ptr()) + idx * size_of(ct_), &c.raw().v, size_of(ct_), current_stream()));
+    }
+    CellBuffer convert(CellType cell_type) const {  // buffer.rs:150-167
+        if (cell_type == ct_) return clone();
+        if (!can_fit_into(ct_, cell_type)) throw NarrowingError(ct_, cell_type);
+        if (n_ == 0) return empty_u8();
+        CellBuffer out(cell_type, n_);
+        check(ec_convert(static_cast<ec_dtype>(ct_), ptr(), static_cast<ec_dtype>(cell_type), out.ptr(), n_, current_stream()));
+        return out;
+    }
+    std::pair<CellValue, CellValue> min_max() const {  // buffer.rs:169-173
+        ec_value mn, mx;
+        check(ec_min_max(static_cast<ec_dtype>(ct_), ptr(), nullptr, n_, &mn, &mx, current_stream()));
+        return {CellValue(mn), CellValue(mx)};
+    }
+    template <typename T> std::vector<T> to_vec() const {  // buffer.rs:175-185
+        CellBuffer r = convert(CellEncoding<T>::cell_type());
+        if (r.cell_type() != CellEncoding<T>::cell_type())  // danger::cast assert (buffer.rs:444)
+            throw std::logic_error("assertion failed: T::cell_type() == P::cell_type()");
+        std::vector<T> out(r.len());
+        check(ec_download(out.data(), r.ptr(), out.size() * sizeof(T), current_stream()));
+        return out;
+    }
+
+    // ---- ops (buffer.rs:321-371)
+    CellBuffer binop(ec_op op, const CellBuffer& rhs) const {
+        size_t n = n_ < rhs.n_ ? n_ : rhs.n_;  // zip (buffer.rs:327)
+        if (n == 0) return empty_u8();
+        CellBuffer out(CellType::Float64, n);
+        check(ec_binop(op, static_cast<ec_dtype>(ct_), ptr(), static_cast<ec_dtype>(rhs.ct_), rhs.ptr(), n,
+                       static_cast<double*>(out.ptr()), current_stream()));
+        return out;
+    }
+    CellBuffer binop(ec_op op, const CellValue& rhs) const {  // RHS scalar (buffer.rs:346-352)
+        if (n_ == 0) return empty_u8();
+        CellBuffer out(CellType::Float64, n_);
+        check(ec_binop_scalar(op, static_cast<ec_dtype>(ct_), ptr(), n_, &rhs.raw(), static_cast<double*>(out.ptr()), current_stream()));
+        return out;
+    }
+    CellBuffer neg() const {  // buffer.rs:360-365
+        if (n_ == 0) return empty_u8();
+        CellBuffer out(static_cast<CellType>(ec_neg_result_type(static_cast<ec_dtype>(ct_))), n_);
+        check(ec_neg(static_cast<ec_dtype>(ct_), ptr(), n_, out.ptr(), current_stream()));
+        return out;
+    }
+
+    // ---- Ord/Eq (buffer.rs:373-436): cell type first, then lexicographic total order, then length
+    int cmp(const CellBuffer& o) const {
+        if (ct_ != o.ct_) return ct_ < o.ct_ ? -1 : 1;
+        size_t sz = size_of(ct_), n = n_ < o.n_ ? n_ : o.n_;
+        std::vector<unsigned char> a(n_ * sz), b(o.n_ * sz);
+        check(ec_download(a.data(), ptr(), a.size(), current_stream()));
+        check(ec_download(b.data(), o.ptr(), b.size(), current_stream()));
+        for (size_t i = 0; i < n; ++i) {
+            ec_value x{}, y{};
+            x.dtype = y.dtype = static_cast<uint8_t>(ct_);
+            std::memcpy(&x.v, a.data() + i * sz, sz);
+            std::memcpy(&y.v, b.data() + i * sz, sz);
+            int c = CellValue(x).cmp(CellValue(y));
+            if (c) return c;
+        }
+        return (n_ > o.n_) - (n_ < o.n_);
+    }
+    bool operator==(const CellBuffer& o) const { return cmp(o) == 0; }
+    bool operator!=(const CellBuffer& o) const { return cmp(o) != 0; }
+    bool operator<(const CellBuffer& o) const { return cmp(o) < 0; }
+    bool operator>(const CellBuffer& o) const { return cmp(o) > 0; }
+};
+
+#define EC_CB_OP(OPSYM, OPC)                                                                            \
+    inline CellBuffer operator OPSYM(const CellBuffer& l, const CellBuffer& r) { return l.binop(OPC, r); } \
+    inline CellBuffer operator OPSYM(const CellBuffer& l, const CellValue& r) { return l.binop(OPC, r); }  \
+    template <typename R, typename = decltype(CellEncoding<R>::cell_type())>                            \
+    inline CellBuffer operator OPSYM(const CellBuffer& l, R r) { return l.binop(OPC, CellValue(r)); }
+EC_CB_OP(+, EC_ADD) EC_CB_OP(-, EC_SUB) EC_CB_OP(*, EC_MUL) EC_CB_OP(/, EC_DIV)
+#undef EC_CB_OP
+inline CellBuffer operator-(const CellBuffer& b) { return b.neg(); }
+
+// ---------------------------------------------------------------- Mask (src/masked/mask.rs)
+class Mask {
+    size_t n_ = 0;
+    std::shared_ptr<DeviceMem> mem_;
+
+public:
+    Mask() : mem_(std::make_shared<DeviceMem>(0)) {}
+    explicit Mask(size_t n) : n_(n), mem_(std::make_shared<DeviceMem>(n)) {}
+    Mask(Mask&&) = default;
+    Mask& operator=(Mask&&) = default;
+    Mask(const Mask&) = delete;
+    Mask& operator=(const Mask&) = delete;
+    uint8_t* ptr() const { return static_cast<uint8_t*>(mem_->ptr()); }
+
+    static Mask new_(const std::vector<bool>& values) {  // mask.rs:16-18
+        std::vector<uint8_t> b(values.begin(), values.end());
+        Mask m(b.size());
+        check(ec_upload(m.ptr(), b.data(), b.size(), current_stream()));
+        return m;
+    }
+    static Mask fill(size_t len, bool value) {  // mask.rs:21-23
+        Mask m(len);
+        CellValue v(static_cast<uint8_t>(value ? 1 : 0));
+        check(ec_fill(EC_U8, m.ptr(), len, &v.raw(), current_stream()));
+        return m;
+    }
+    template <typename F> static Mask fill_via(size_t len, F f) {  // mask.rs:28-33
+        std::vector<bool> v(len);
+        for (size_t i = 0; i < len; ++i) v[i] = f(i);
+        return new_(v);
+    }
+    size_t len() const { return n_; }
+    bool is_empty() const { return n_ == 0; }
+    Mask clone() const {
+        Mask m(n_);
+        check(ec_copy(m.ptr(), ptr(), n_, current_stream()));
+        return m;
+    }
+    void put(size_t index, bool value) {  // mask.rs:49-51
+        if (index >= n_) throw std::out_of_range("index out of bounds");
+        uint8_t b = value;
+        check(ec_upload(ptr() + index, &b, 1, current_stream()));
+    }
+    bool get(size_t index) const {  // mask.rs:57-59
+        if (index >= n_) throw std::out_of_range("index out of bounds");
+        uint8_t b = 0;
+        check(ec_download(&b, ptr() + index, 1, current_stream()));
+        return b != 0;
+    }
+    std::pair<size_t, size_t> counts() const {  // mask.rs:72-80
+        uint64_t t = 0, f = 0;
+        check(ec_mask_counts(ptr(), n_, &t, &f, current_stream()));
+        return {t, f};
+    }
+    bool all(bool value) const { auto [t, f] = counts(); return value ? f == 0 : t == 0; }  // mask.rs:67-69
+    std::vector<bool> to_vec() const {
+        std::vector<uint8_t> b(n_);
+        check(ec_download(b.data(), ptr(), n_, current_stream()));
+        return std::vector<bool>(b.begin(), b.end());
+    }
+    bool operator==(const Mask& o) const { return n_ == o.n_ && to_vec() == o.to_vec(); }
+    bool operator!=(const Mask& o) const { return !(*this == o); }
+
+    Mask operator!() const& {  // Not for &Mask (mask.rs:111-116)
+        Mask m(n_);
+        check(ec_mask_not(ptr(), n_, m.ptr(), current_stream()));
+        return m;
+    }
+    Mask operator!() && {  // Not for Mask: in place (mask.rs:103-109)
+        check(ec_mask_not(ptr(), n_, ptr(), current_stream()));
+        return std::move(*this);
+    }
+};
+inline Mask operator&(const Mask& l, const Mask& r) {  // BitAnd for &Mask: zip -> shorter (mask.rs:129-140)
+    size_t n = l.len() < r.len() ? l.len() : r.len();
+    Mask m(n);
+    check(ec_mask_and(l.ptr(), r.ptr(), n, m.ptr(), current_stream()));
+    return m;
+}
+inline Mask operator|(const Mask& l, const Mask& r) {  // BitOr for &Mask (mask.rs:153-163)
+    size_t n = l.len() < r.len() ? l.len() : r.len();
+    Mask m(n);
+    check(ec_mask_or(l.ptr(), r.ptr(), n, m.ptr(), current_stream()));
+    return m;
+}
+inline Mask operator&(Mask&& l, const Mask& r) {  // BitAnd for Mask (owned, in place, lhs length kept — mask.rs:118-127)
+    check(ec_mask_and(l.ptr(), r.ptr(), l.len() < r.len() ? l.len() : r.len(), l.ptr(), current_stream()));
+    return std::move(l);
+}
+inline Mask operator|(Mask&& l, const Mask& r) {  // mask.rs:142-151
+    check(ec_mask_or(l.ptr(), r.ptr(), l.len() < r.len() ? l.len() : r.len(), l.ptr(), current_stream()));
+    return std::move(l);
+}
+
+// ---------------------------------------------------------------- MaskedCellBuffer (src/masked/masked_buffer.rs)
+class MaskedCellBuffer {
+    CellBuffer buf_;
+    Mask mask_;
+
+public:
+    MaskedCellBuffer(CellBuffer buffer, Mask mask) : buf_(std::move(buffer)), mask_(std::move(mask)) {  // :48-55
+        if (buf_.len() != mask_.len()) throw std::logic_error("Mask and buffer must have the same length.");
+    }
+    static MaskedCellBuffer new_(CellBuffer b, Mask m) { return MaskedCellBuffer(std::move(b), std::move(m)); }
+    MaskedCellBuffer(MaskedCellBuffer&&) = default;
+    MaskedCellBuffer& operator=(MaskedCellBuffer&&) = default;
+    MaskedCellBuffer clone() const { return MaskedCellBuffer(buf_.clone(), mask_.clone()); }
+
+    template <typename T> static MaskedCellBuffer from_vec(const std::vector<T>& data) {  // :156-160
+        CellBuffer b = CellBuffer::from_vec(data);
+        size_t n = b.len();
+        return MaskedCellBuffer(std::move(b), Mask::fill(n, true));
+    }
+    static MaskedCellBuffer from(CellBuffer b) {  // From<CellBuffer> (:250-255)
+        size_t n = b.len();
+        return MaskedCellBuffer(std::move(b), Mask::fill(n, true));
+    }
+    template <typename T> static MaskedCellBuffer from_vec_with_nodata(const std::vector<T>& data, NoData<T> nodata) {  // :62-71
+        CellBuffer b = CellBuffer::from_vec(data);
+        Mask m(b.len());
+        auto nd = nodata.value();
+        CellValue ndv = nd ? CellValue(*nd) : CellValue();
+        check(ec_mask_from_nodata(static_cast<ec_dtype>(b.cell_type()), b.ptr(), b.len(), nd ? &ndv.raw() : nullptr, m.ptr(), current_stream()));
+        return MaskedCellBuffer(std::move(b), std::move(m));
+    }
+    static MaskedCellBuffer with_defaults(size_t len, CellType ct) { return from(CellBuffer::with_defaults(len, ct)); }
+    static MaskedCellBuffer fill(size_t len, const CellValue& v) { return from(CellBuffer::fill(len, v)); }
+    template <typename T, typename F> static MaskedCellBuffer fill_via(size_t len, F f) { return from(CellBuffer::fill_via<T>(len, f)); }
+    template <typename T, typename F> static MaskedCellBuffer fill_with_mask_via(size_t len, F mv) {  // :73-79
+        std::vector<T> v(len);
+        std::vector<bool> m(len);
+        for (size_t i = 0; i < len; ++i) { auto p = mv(i); v[i] = p.first; m[i] = p.second; }
+        return MaskedCellBuffer(CellBuffer::from_vec(v), Mask::new_(m));
+    }
+
+    const CellBuffer& buffer() const { return buf_; }
+    CellBuffer& buffer_mut() { return buf_; }
+    const Mask& mask() const { return mask_; }
+    Mask& mask_mut() { return mask_; }
+    size_t len() const { return buf_.len(); }
+    CellType cell_type() const { return buf_.cell_type(); }
+    CellValue get(size_t i) const { return buf_.get(i); }
+    void put(size_t i, const CellValue& v) { buf_.put(i, v); }
+    std::optional<CellValue> get_masked(size_t i) const {  // :100-106
+        if (mask_.get(i)) return buf_.get(i);
+        return std::nullopt;
+    }
+    std::pair<CellValue, bool> get_with_mask(size_t i) const { return {buf_.get(i), mask_.get(i)}; }
+    void put_with_mask(size_t i, const CellValue& v, bool m) { put(i, v); mask_.put(i, m); }  // :120-129
+    std::pair<size_t, size_t> counts() const { return mask_.counts(); }                       // :132-134
+    MaskedCellBuffer convert(CellType ct) const { return MaskedCellBuffer(buf_.convert(ct), mask_.clone()); }  // :200-206
+    template <typename T> std::vector<T> to_vec() const { return buf_.to_vec<T>(); }
+    template <typename T> std::vector<T> to_vec_with_nodata(NoData<T> no_data) const {  // :137-152
+        CellBuffer conv = buf_.convert(CellEncoding<T>::cell_type());
+        if (conv.cell_type() != CellEncoding<T>::cell_type()) throw std::logic_error("assertion failed: T::cell_type() == P::cell_type()");
+        auto nd = no_data.value();
+        std::vector<T> out(conv.len());
+        if (!nd) {
+            check(ec_download(out.data(), conv.ptr(), out.size() * sizeof(T), current_stream()));
+            return out;
+        }
+        CellBuffer sel(conv.cell_type(), conv.len());
+        CellValue ndv(*nd);
+        check(ec_mask_select(static_cast<ec_dtype>(conv.cell_type()), conv.ptr(), mask_.ptr(), conv.len(), &ndv.raw(), sel.ptr(), current_stream()));
+        check(ec_download(out.data(), sel.ptr(), out.size() * sizeof(T), current_stream()));
+        return out;
+    }
+    std::pair<CellValue, CellValue> min_max() const {  // :208-217
+        ec_value mn, mx;
+        check(ec_min_max(static_cast<ec_dtype>(cell_type()), buf_.ptr(), mask_.ptr(), len(), &mn, &mx, current_stream()));
+        return {CellValue(mn), CellValue(mx)};
+    }
+
+    // ---- ops (:323-383)
+    MaskedCellBuffer binop(ec_op op, const MaskedCellBuffer& rhs) const {
+        size_t n = len() < rhs.len() ? len() : rhs.len();
+        if (n == 0) return MaskedCellBuffer(CellBuffer(CellType::UInt8, 0), Mask(0));
+        CellBuffer out(CellType::Float64, n);
+        Mask om(n);
+        check(ec_masked_binop(op, static_cast<ec_dtype>(cell_type()), buf_.ptr(), mask_.ptr(), static_cast<ec_dtype>(rhs.cell_type()),
+                              rhs.buf_.ptr(), rhs.mask_.ptr(), n, static_cast<double*>(out.ptr()), om.ptr(), current_stream()));
+        return MaskedCellBuffer(std::move(out), std::move(om));
+    }
+    MaskedCellBuffer binop(ec_op op, const CellValue& rhs) const { return MaskedCellBuffer(buf_.binop(op, rhs), mask_.clone()); }
+    MaskedCellBuffer neg() const { return MaskedCellBuffer(buf_.neg(), mask_.clone()); }
+    bool operator==(const MaskedCellBuffer& o) const { return buf_ == o.buf_ && mask_ == o.mask_; }  // derived PartialEq (:39)
+    bool operator!=(const MaskedCellBuffer& o) const { return !(*this == o); }
+};
+
+#define EC_MCB_OP(OPSYM, OPC)                                                                                          \
+    inline MaskedCellBuffer operator OPSYM(const MaskedCellBuffer& l, const MaskedCellBuffer& r) { return l.binop(OPC, r); } \
+    inline MaskedCellBuffer operator OPSYM(const MaskedCellBuffer& l, const CellValue& r) { return l.binop(OPC, r); }        \
+    template <typename R, typename = decltype(CellEncoding<R>::cell_type())>                                            \
+    inline MaskedCellBuffer operator OPSYM(const MaskedCellBuffer& l, R r) { return l.binop(OPC, CellValue(r)); }
+EC_MCB_OP(+, EC_ADD) EC_MCB_OP(-, EC_SUB) EC_MCB_OP(*, EC_MUL) EC_MCB_OP(/, EC_DIV)
+#undef EC_MCB_OP
+inline MaskedCellBuffer operator-(const MaskedCellBuffer& b) { return b.neg(); }
+
+}  // namespace erased_cells
