@@ -48,7 +48,6 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: one side² raster row-sharded over the ranks (default); weak: side² per rank")
     ap.add_argument("--variant", type=int, default=None, help="binop kernel variant: 0 direct, 1 LDS-staged")
-    ap.add_argument("--bpc", type=int, default=None, help="blocks-per-CU cap (0 = one block per tile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -132,8 +131,6 @@ def main():
     L = ec.lib()
     if args.variant is not None:
         ec._ffi.check(L.ec_tune_set(b"binop_variant", args.variant))
-    if args.bpc is not None:
-        ec._ffi.check(L.ec_tune_set(b"bpc", args.bpc))
     stream = torch.cuda.current_stream().cuda_stream
     ec.set_stream(stream)
 

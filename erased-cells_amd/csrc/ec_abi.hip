@@ -89,11 +89,11 @@ template <typename Fn>
 static ec_status launch_map(const Fn& fn, size_t n, bool aligned, hipStream_t s, const char* what) {
     if (n == 0) return EC_OK;
     if (!aligned) {
-        k_map_cellwise<Fn><<<grid_for((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fn, n);
+        k_map_cellwise<Fn><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fn, n);
     } else {
         const size_t groups = n / Fn::CPL;
         const size_t tiles = (groups + size_t(kBlock) * kMapU - 1) / (size_t(kBlock) * kMapU);
-        k_map<Fn, kMapU><<<grid_for(tiles, g_tuning.bpc), kBlock, 0, s>>>(fn, n);
+        k_map<Fn, kMapU><<<grid_for(tiles), kBlock, 0, s>>>(fn, n);
     }
     return check_launch(what);
 }
@@ -389,7 +389,6 @@ extern "C" ec_status ec_stream_sync(ec_stream s) { return check_hip(hipStreamSyn
 extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     if (!key) return set_error(EC_ERR_ARG, "ec_tune_set: null key");
     if (!std::strcmp(key, "binop_variant")) g_tuning.binop_variant = static_cast<int>(value);
-    else if (!std::strcmp(key, "bpc")) g_tuning.bpc = static_cast<int>(value);
     else if (!std::strcmp(key, "reduce_bpc")) g_tuning.reduce_bpc = value > 0 ? static_cast<int>(value) : 8;
     else return set_error(EC_ERR_ARG, "ec_tune_set: unknown key '%s'", key);
     return EC_OK;

@@ -18,17 +18,17 @@ static ec_status launch_binop_pair(const void* l, const void* r, size_t n, doubl
     const R* rp = static_cast<const R*>(r);
     constexpr int U = kBinopU;
     if (!aligned16(l, r, out)) {
-        k_binop_cellwise<L, R, OP><<<grid_for((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, rp, out, n);
+        k_binop_cellwise<L, R, OP><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, rp, out, n);
         return check_launch("binop(cellwise)");
     }
     constexpr bool kCanStage = Staged<L, U>::value || Staged<R, U>::value;
     if (kCanStage && tu.binop_variant == 1) {
         const size_t tiles = (n / (128 * size_t(U)) + kWavesPerBlock - 1) / kWavesPerBlock;
-        k_binop_lds<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, rp, out, n);
+        k_binop_lds<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n);
         return check_launch("binop(lds)");
     }
     const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
-    k_binop_direct<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, rp, out, n);
+    k_binop_direct<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n);
     return check_launch("binop(direct)");
 }
 
@@ -40,31 +40,30 @@ static ec_status launch_masked_pair(const void* l, const uint8_t* lm, const void
     const R* rp = static_cast<const R*>(r);
     constexpr int U = kBinopU;
     if (!aligned16(l, r, out) || !aligned16(lm, rm, om)) {
-        k_masked_binop_cellwise<L, R, OP><<<grid_for((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
+        k_masked_binop_cellwise<L, R, OP><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
         return check_launch("masked_binop(cellwise)");
     }
     constexpr bool kCanStage = Staged<L, U>::value || Staged<R, U>::value;
     if (kCanStage && tu.binop_variant == 1) {
         const size_t tiles = (n / (128 * size_t(U)) + kWavesPerBlock - 1) / kWavesPerBlock;
-        k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, true><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
+        k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, true><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
         return check_launch("masked_binop(lds)");
     }
     const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
-    k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, false><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
+    k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, false><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
     return check_launch("masked_binop(direct)");
 }
 
 template <typename L, int OP>
 static ec_status launch_scalar(const void* l, double rhs, size_t n, double* out, hipStream_t s) {
-    const Tuning& tu = tuning();
     const L* lp = static_cast<const L*>(l);
     constexpr int U = kBinopU;
     if (!aligned16(l, out, out)) {
-        k_binop_scalar_cellwise<L, OP><<<grid_for((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, rhs, out, n);
+        k_binop_scalar_cellwise<L, OP><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, rhs, out, n);
         return check_launch("binop_scalar(cellwise)");
     }
     const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
-    k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles, tu.bpc), kBlock, 0, s>>>(lp, rhs, out, n);
+    k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rhs, out, n);
     return check_launch("binop_scalar(direct)");
 }
 

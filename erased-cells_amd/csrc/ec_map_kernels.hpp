@@ -6,9 +6,10 @@
 // access (CPL = 16 / widest cell cells per lane); the narrower streams then move
 // CPL*width bytes per lane, still lane-contiguous, so every wave instruction
 // touches one contiguous span.  A block tile is U such groups per lane, loads
-// first, then compute + stores; tiles are dealt round-robin to a grid capped at
-// a few blocks per CU.  Ragged tails and unaligned pointers take the cell-wise
-// kernel (correct for any alignment, one cell per lane).
+// first, then compute + stores; one workgroup per tile, straight-line, with
+// non-temporal loads and stores (every byte is touched once).  Ragged tails are
+// guarded in the last tile; unaligned pointers take the cell-wise kernel
+// (correct for any alignment, one cell per lane).
 #pragma once
 
 #include "ec_binop_kernels.hpp"
@@ -27,21 +28,19 @@ __global__ __launch_bounds__(kBlock) void k_map(Fn fn, size_t n) {
     constexpr size_t CPL = Fn::CPL;
     const size_t ngroups = n / CPL;
     constexpr size_t TILE = size_t(kBlock) * U;
-    const size_t ntiles = (ngroups + TILE - 1) / TILE;
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const size_t base = tile * TILE + threadIdx.x;
-        if (tile * TILE + TILE <= ngroups) {
-            In x[U];
+    const size_t tile = blockIdx.x;  // one workgroup per tile, straight-line
+    const size_t base = tile * TILE + threadIdx.x;
+    if (tile * TILE + TILE <= ngroups) {
+        In x[U];
 #pragma unroll
-            for (int j = 0; j < U; ++j) x[j] = fn.load(base + size_t(j) * kBlock);
+        for (int j = 0; j < U; ++j) x[j] = fn.load(base + size_t(j) * kBlock);
 #pragma unroll
-            for (int j = 0; j < U; ++j) fn.store(base + size_t(j) * kBlock, x[j]);
-        } else {
+        for (int j = 0; j < U; ++j) fn.store(base + size_t(j) * kBlock, x[j]);
+    } else {
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const size_t g = base + size_t(j) * kBlock;
-                if (g < ngroups) fn.store(g, fn.load(g));
-            }
+        for (int j = 0; j < U; ++j) {
+            const size_t g = base + size_t(j) * kBlock;
+            if (g < ngroups) fn.store(g, fn.load(g));
         }
     }
     if (blockIdx.x == 0)
@@ -67,9 +66,9 @@ struct ConvertFn {
     using In = SV;
     const S* __restrict__ src;
     D* __restrict__ dst;
-    __device__ __forceinline__ In load(size_t g) const { return reinterpret_cast<const SV*>(src)[g]; }
+    __device__ __forceinline__ In load(size_t g) const { return __builtin_nontemporal_load(reinterpret_cast<const SV*>(src) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
-        reinterpret_cast<DV*>(dst)[g] = __builtin_convertvector(x, DV);
+        __builtin_nontemporal_store(__builtin_convertvector(x, DV), reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = static_cast<D>(src[i]); }
 };
@@ -106,12 +105,12 @@ struct NegFn {
     using In = SV;
     const T* __restrict__ src;
     O* __restrict__ dst;
-    __device__ __forceinline__ In load(size_t g) const { return reinterpret_cast<const SV*>(src)[g]; }
+    __device__ __forceinline__ In load(size_t g) const { return __builtin_nontemporal_load(reinterpret_cast<const SV*>(src) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         DV o;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = neg_cell<T>(x[k]);
-        reinterpret_cast<DV*>(dst)[g] = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = neg_cell<T>(src[i]); }
 };
@@ -129,7 +128,7 @@ struct FillFn {
         DV o;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = value;
-        reinterpret_cast<DV*>(dst)[g] = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = value; }
 };
@@ -146,12 +145,12 @@ struct MaskFromNodataFn {
     const W* __restrict__ src;
     uint8_t* __restrict__ mask;
     W nd;
-    __device__ __forceinline__ In load(size_t g) const { return reinterpret_cast<const SV*>(src)[g]; }
+    __device__ __forceinline__ In load(size_t g) const { return __builtin_nontemporal_load(reinterpret_cast<const SV*>(src) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         MV m;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) m[k] = x[k] != nd;
-        reinterpret_cast<MV*>(mask)[g] = m;
+        __builtin_nontemporal_store(m, reinterpret_cast<MV*>(mask) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { mask[i] = src[i] != nd; }
 };
@@ -168,13 +167,14 @@ struct MaskSelectFn {
     W* __restrict__ dst;
     W nd;
     __device__ __forceinline__ In load(size_t g) const {
-        return In{reinterpret_cast<const SV*>(src)[g], reinterpret_cast<const MV*>(mask)[g]};
+        return In{__builtin_nontemporal_load(reinterpret_cast<const SV*>(src) + g),
+                  __builtin_nontemporal_load(reinterpret_cast<const MV*>(mask) + g)};
     }
     __device__ __forceinline__ void store(size_t g, const In& in) const {
         SV o;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = in.m[k] ? in.x[k] : nd;
-        reinterpret_cast<SV*>(dst)[g] = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<SV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = mask[i] ? src[i] : nd; }
 };
@@ -188,10 +188,11 @@ struct MaskBin {
     const uint8_t* __restrict__ r;
     uint8_t* __restrict__ out;
     __device__ __forceinline__ In load(size_t g) const {
-        return In{reinterpret_cast<const u32x4*>(l)[g], reinterpret_cast<const u32x4*>(r)[g]};
+        return In{__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(l) + g),
+                  __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r) + g)};
     }
     __device__ __forceinline__ void store(size_t g, const In& in) const {
-        reinterpret_cast<u32x4*>(out)[g] = KIND == 0 ? (in.a & in.b) : (in.a | in.b);
+        __builtin_nontemporal_store(KIND == 0 ? (in.a & in.b) : (in.a | in.b), reinterpret_cast<u32x4*>(out) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { out[i] = KIND == 0 ? (l[i] & r[i]) : (l[i] | r[i]); }
 };
@@ -201,9 +202,9 @@ struct MaskNot {
     using In = u32x4;
     const uint8_t* __restrict__ m;
     uint8_t* __restrict__ out;
-    __device__ __forceinline__ In load(size_t g) const { return reinterpret_cast<const u32x4*>(m)[g]; }
+    __device__ __forceinline__ In load(size_t g) const { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(m) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
-        reinterpret_cast<u32x4*>(out)[g] = x ^ 0x01010101u;
+        __builtin_nontemporal_store(x ^ 0x01010101u, reinterpret_cast<u32x4*>(out) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { out[i] = m[i] ^ 1; }
 };
@@ -227,7 +228,7 @@ struct SynthFn {
         DV o;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = gen(g * CPL + k);
-        reinterpret_cast<DV*>(dst)[g] = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = gen(i); }
 };
@@ -245,7 +246,7 @@ struct SynthMaskFn {
         DV o;
 #pragma unroll
         for (int k = 0; k < 16; ++k) o[k] = gen(g * 16 + k);
-        reinterpret_cast<DV*>(dst)[g] = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = gen(i); }
 };

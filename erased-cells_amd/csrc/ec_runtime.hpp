@@ -14,14 +14,13 @@ namespace ecd {
 // A/B runs recorded in profiles/ (tools/tune_binop.hip).
 constexpr int kBinopU = 8;         // chunks of 128 cells per wave per tile
 constexpr bool kNtStore = true;    // streaming f64 output: 2.1 GB ≫ 256 MiB Infinity Cache
-constexpr bool kNtLoad = false;
+constexpr bool kNtLoad = true;     // +6 % on the divide (tune_binop_v2.log: 6270 -> 6666 GB/s)
 constexpr int kMapU = 4;           // groups per lane per tile for the map kernels
 constexpr int kReduceU = 4;
 constexpr int kMaxReduceBlocks = 4096;
 
 struct Tuning {
     int binop_variant = 0;  // 0 = direct narrow loads, 1 = LDS-staged narrow operands
-    int bpc = 0;            // blocks per CU cap for element-wise grids; 0 = one block per tile
     int reduce_bpc = 8;     // blocks per CU for reductions (partials are per block)
 };
 
@@ -37,12 +36,16 @@ inline bool aligned16(const void* a, const void* b, const void* c) {
     return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15u) == 0;
 }
 
-// Grid for `tiles` block tiles: all of them, or capped at bpc blocks per CU
-// (the kernels grid-stride over tiles either way).
-inline unsigned grid_for(size_t tiles, int bpc) {
+// Element-wise kernels: one workgroup per tile.
+inline unsigned grid_for(size_t tiles) {
     if (tiles < 1) tiles = 1;
-    size_t cap = bpc > 0 ? size_t(device_cus()) * size_t(bpc) : size_t(0x7fffffff);
-    return static_cast<unsigned>(tiles < cap ? tiles : cap);
+    return static_cast<unsigned>(tiles < size_t(0x7fffffff) ? tiles : size_t(0x7fffffff));
+}
+// Grid-stride kernels (cell-wise fallbacks, reductions): at most bpc workgroups per CU.
+inline unsigned grid_capped(size_t blocks, int bpc) {
+    if (blocks < 1) blocks = 1;
+    const size_t cap = size_t(device_cus()) * size_t(bpc > 0 ? bpc : 8);
+    return static_cast<unsigned>(blocks < cap ? blocks : cap);
 }
 
 // Per-stream scratch for reduction partials (device) and results (pinned host).

@@ -62,13 +62,11 @@ def test_binop_reference_shaped_oracle_and_variants(ec, variant):
         ec.lib().ec_tune_set(b"binop_variant", 0)
 
 
-@pytest.mark.parametrize("bpc", [0, 2])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_binop_lengths_tails_and_alignment(ec, variant, bpc):
+def test_binop_lengths_tails_and_alignment(ec, variant):
     """Ragged sizes around every tile boundary, zip truncation, and odd cell offsets
     (row-block windows that are not 16-byte aligned take the cell-wise kernel)."""
     ec.lib().ec_tune_set(b"binop_variant", variant)
-    ec.lib().ec_tune_set(b"bpc", bpc)
     try:
         big = 2 * 1024 * 1024 + 5
         l, r = eco.fill_u8(big, 0x5EED0001), eco.fill_u16(big, 0x5EED0002, lo=0)  # zeros in the divisor: 0/0, x/0
@@ -89,7 +87,6 @@ def test_binop_lengths_tails_and_alignment(ec, variant, bpc):
         assert e.cell_type() == ec.UInt8 and e.len() == 0
     finally:
         ec.lib().ec_tune_set(b"binop_variant", 0)
-        ec.lib().ec_tune_set(b"bpc", 0)
 
 
 def test_div_by_zero_and_nan_policy(ec):
