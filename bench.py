@@ -48,7 +48,13 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: one side² raster row-sharded over the ranks (default); weak: side² per rank")
     ap.add_argument("--variant", type=int, default=None, help="binop kernel variant: 0 direct, 1 LDS-staged")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; nccl (= RCCL over xGMI) is the product path, gloo only for rehearsals")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses device 0 (implies nothing about scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time from_vec (H2D) + divide + to_vec (D2H) once; reported beside, never as `value`")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -119,15 +125,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     import erased_cells_hip as ec
     from erased_cells_hip import sharded
 
-    ec.init(local_rank)
+    ec.init(dev)
     L = ec.lib()
     if args.variant is not None:
         ec._ffi.check(L.ec_tune_set(b"binop_variant", args.variant))
@@ -229,6 +239,15 @@ def main():
                          "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": n,
                          "launch_ms": launch_ms, "timer": "hipEvent pair on the launch stream over the timed region / steps"},
         }
+        if args.e2e and world == 1 and args.workload == "div_u8_u16":
+            import numpy as np
+            ha, hb = a.to_numpy(), b.to_numpy()
+            t1 = time.perf_counter()
+            r = (ec.CellBuffer.from_vec(ha) / ec.CellBuffer.from_vec(hb)).to_numpy()
+            dt = time.perf_counter() - t1
+            res["end_to_end_pcie"] = {"value": n / dt / 1e9, "unit": "Gcells/s", "seconds": dt,
+                                      "what": "from_vec(u8)+from_vec(u16) over PCIe, divide, to_vec(f64) back; pageable host memory"}
+            del r
         if world == 1 and not args.no_cpu_baseline and args.workload == "div_u8_u16":
             res["cpu_baseline"] = cpu_baseline(side, args.cpu_seconds)
         print(json.dumps(res), flush=True)

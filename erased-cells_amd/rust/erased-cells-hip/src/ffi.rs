@@ -1,0 +1,71 @@
+//! Raw `extern "C"` declarations of include/erased_cells.h (ABI version 1).
+//! Every data pointer is a DEVICE pointer unless the name says `host`.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_void};
+
+pub type ec_status = i32;
+pub type ec_dtype = u8; // `CellType as u8` (src/ctype.rs:16)
+pub type ec_op = i32;
+pub type ec_stream = *mut c_void; // hipStream_t
+
+pub const EC_OK: ec_status = 0;
+pub const EC_ERR_NARROWING: ec_status = 1;
+pub const EC_ADD: ec_op = 0;
+pub const EC_SUB: ec_op = 1;
+pub const EC_MUL: ec_op = 2;
+pub const EC_DIV: ec_op = 3;
+
+/// Mirrors `ec_value`: tag + 8-byte payload, 16 bytes.
+#[repr(C)]
+#[derive(Copy, Clone)]
+pub struct ec_value {
+    pub dtype: u8,
+    pub pad_: [u8; 7],
+    pub bits: u64, // the C union; read/written through to_bits()/from_bits() of the primitive
+}
+
+extern "C" {
+    pub fn ec_abi_version() -> i32;
+    pub fn ec_init(device: i32) -> ec_status;
+    pub fn ec_shutdown() -> ec_status;
+    pub fn ec_last_error_string() -> *const c_char;
+    pub fn ec_last_narrowing(src: *mut ec_dtype, dst: *mut ec_dtype) -> ec_status;
+
+    pub fn ec_alloc(dptr: *mut *mut c_void, bytes: usize) -> ec_status;
+    pub fn ec_free(dptr: *mut c_void) -> ec_status;
+    pub fn ec_upload(dst_dev: *mut c_void, src_host: *const c_void, bytes: usize, s: ec_stream) -> ec_status;
+    pub fn ec_download(dst_host: *mut c_void, src_dev: *const c_void, bytes: usize, s: ec_stream) -> ec_status;
+    pub fn ec_copy(dst_dev: *mut c_void, src_dev: *const c_void, bytes: usize, s: ec_stream) -> ec_status;
+
+    pub fn ec_union(a: ec_dtype, b: ec_dtype) -> ec_dtype;
+    pub fn ec_can_fit_into(src: ec_dtype, dst: ec_dtype) -> i32;
+    pub fn ec_neg_result_type(t: ec_dtype) -> ec_dtype;
+
+    pub fn ec_binop(op: ec_op, lt: ec_dtype, l: *const c_void, rt: ec_dtype, r: *const c_void, n: usize,
+                    out: *mut f64, s: ec_stream) -> ec_status;
+    pub fn ec_binop_scalar(op: ec_op, lt: ec_dtype, l: *const c_void, n: usize, rhs: *const ec_value,
+                           out: *mut f64, s: ec_stream) -> ec_status;
+    pub fn ec_masked_binop(op: ec_op, lt: ec_dtype, l: *const c_void, lmask: *const u8, rt: ec_dtype,
+                           r: *const c_void, rmask: *const u8, n: usize, out: *mut f64, out_mask: *mut u8,
+                           s: ec_stream) -> ec_status;
+    pub fn ec_neg(t: ec_dtype, input: *const c_void, n: usize, out: *mut c_void, s: ec_stream) -> ec_status;
+    pub fn ec_convert(st: ec_dtype, src: *const c_void, dt: ec_dtype, dst: *mut c_void, n: usize, s: ec_stream) -> ec_status;
+    pub fn ec_fill(t: ec_dtype, dst: *mut c_void, n: usize, value: *const ec_value, s: ec_stream) -> ec_status;
+
+    pub fn ec_min_max(t: ec_dtype, p: *const c_void, mask_or_null: *const u8, n: usize, mn: *mut ec_value,
+                      mx: *mut ec_value, s: ec_stream) -> ec_status;
+    pub fn ec_min_max_keys(t: ec_dtype, p: *const c_void, mask_or_null: *const u8, n: usize, keys2_dev: *mut i64,
+                           s: ec_stream) -> ec_status;
+    pub fn ec_min_max_decode(t: ec_dtype, keys2_host: *const i64, mn: *mut ec_value, mx: *mut ec_value) -> ec_status;
+
+    pub fn ec_mask_from_nodata(t: ec_dtype, p: *const c_void, n: usize, nd_or_null: *const ec_value, mask: *mut u8,
+                               s: ec_stream) -> ec_status;
+    pub fn ec_mask_select(t: ec_dtype, p: *const c_void, mask: *const u8, n: usize, nd_or_null: *const ec_value,
+                          out: *mut c_void, s: ec_stream) -> ec_status;
+    pub fn ec_mask_and(l: *const u8, r: *const u8, n: usize, out: *mut u8, s: ec_stream) -> ec_status;
+    pub fn ec_mask_or(l: *const u8, r: *const u8, n: usize, out: *mut u8, s: ec_stream) -> ec_status;
+    pub fn ec_mask_not(m: *const u8, n: usize, out: *mut u8, s: ec_stream) -> ec_status;
+    pub fn ec_mask_counts(m: *const u8, n: usize, n_true: *mut u64, n_false: *mut u64, s: ec_stream) -> ec_status;
+    pub fn ec_shard_range(n_rows: u64, n_cols: u64, shard: u32, n_shards: u32, cell_offset: *mut u64,
+                          cell_len: *mut u64) -> ec_status;
+}
