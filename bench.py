@@ -8,7 +8,7 @@ is cut into N contiguous row-blocks (one process / GPU); the divide
 needs no data-path collective.  Scaling is therefore "strong": the raster is
 fixed at 16384² (north_star) and each rank owns rows/N of it.
 
-  python bench.py --gpus 1 --steps 50 --warmup 5
+  python bench.py --gpus 1 --steps 200 --warmup 60
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -41,8 +41,10 @@ METRIC = "Gcells/s + HBM-GB/s roofline %, u8/u16->f64 16384^2, 1/2/4/8 GPUs"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: the first ~50 launches (≈25 ms) after idle run ≈5 % slow while the clocks ramp
+    # (profiles/r01/warmup_sensitivity.txt), so warm up past that by default
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--side", type=int, default=16384, help="raster is side x side cells")
     ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],

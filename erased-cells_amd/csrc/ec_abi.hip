@@ -85,15 +85,24 @@ ec_status get_scratch(hipStream_t s, Scratch* out) {
 
 static inline hipStream_t S(ec_stream s) { return static_cast<hipStream_t>(s); }
 
+template <typename Fn, int U>
+static void launch_map_u(const Fn& fn, size_t n, hipStream_t s) {
+    const size_t groups = n / Fn::CPL;
+    const size_t tiles = (groups + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
+    k_map<Fn, U><<<grid_for(tiles), kBlock, 0, s>>>(fn, n);
+}
+
 template <typename Fn>
 static ec_status launch_map(const Fn& fn, size_t n, bool aligned, hipStream_t s, const char* what) {
     if (n == 0) return EC_OK;
     if (!aligned) {
         k_map_cellwise<Fn><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fn, n);
     } else {
-        const size_t groups = n / Fn::CPL;
-        const size_t tiles = (groups + size_t(kBlock) * kMapU - 1) / (size_t(kBlock) * kMapU);
-        k_map<Fn, kMapU><<<grid_for(tiles), kBlock, 0, s>>>(fn, n);
+        switch (g_tuning.map_u) {  // groups of 16 B per lane per tile
+            case 1: launch_map_u<Fn, 1>(fn, n, s); break;
+            case 4: launch_map_u<Fn, 4>(fn, n, s); break;
+            default: launch_map_u<Fn, 2>(fn, n, s); break;
+        }
     }
     return check_launch(what);
 }
@@ -390,6 +399,7 @@ extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     if (!key) return set_error(EC_ERR_ARG, "ec_tune_set: null key");
     if (!std::strcmp(key, "binop_variant")) g_tuning.binop_variant = static_cast<int>(value);
     else if (!std::strcmp(key, "reduce_bpc")) g_tuning.reduce_bpc = value > 0 ? static_cast<int>(value) : 8;
+    else if (!std::strcmp(key, "map_u")) g_tuning.map_u = static_cast<int>(value);
     else return set_error(EC_ERR_ARG, "ec_tune_set: unknown key '%s'", key);
     return EC_OK;
 }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kBlock) void k_map(Fn fn, size_t n) {
     constexpr size_t CPL = Fn::CPL;
     const size_t ngroups = n / CPL;
     constexpr size_t TILE = size_t(kBlock) * U;
-    const size_t tile = blockIdx.x;  // one workgroup per tile, straight-line
+    const size_t tile = two_front_tile();  // one workgroup per tile, straight-line
     const size_t base = tile * TILE + threadIdx.x;
     if (tile * TILE + TILE <= ngroups) {
         In x[U];

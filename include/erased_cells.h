@@ -183,7 +183,8 @@ ec_status ec_synth_fill(ec_dtype t, void *dst, size_t n, uint64_t seed, uint64_t
                         double lo, double hi, ec_stream stream);
 /* mask[i] = splitmix64(seed ^ (base+i)) % 100 >= pct_nodata */
 ec_status ec_synth_mask(uint8_t *dst, size_t n, uint64_t seed, uint64_t base, uint32_t pct_nodata, ec_stream stream);
-/* Tuning knobs: "binop_variant" (0 direct narrow loads, 1 LDS-staged), "reduce_bpc" (workgroups per CU for reductions). */
+/* Tuning knobs: "binop_variant" (0 direct narrow loads, 1 LDS-staged), "reduce_bpc" (workgroups per CU for reductions),
+ * "map_u" (16-B groups per lane per tile of the map kernels: 1, 2 or 4). */
 ec_status ec_tune_set(const char *key, int64_t value);
 
 #ifdef __cplusplus

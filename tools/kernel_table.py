@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Per-kernel-family roofline table (dev tool): times every kernel family of the library at
+16384² cells through the C ABI with HIP events and prints achieved GB/s against the 8 TB/s peak,
+using the algorithmic bytes per cell of SURVEY §8(d).
+
+    python tools/kernel_table.py [side] > gpurun_out/kernel_table.md
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "erased-cells_amd", "python"))
+
+import torch  # noqa: E402
+
+import erased_cells_hip as ec  # noqa: E402
+
+PEAK = 8000.0
+SZ = [1, 2, 4, 8, 1, 2, 4, 8, 4, 8]
+
+
+def main():
+    side = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    map_u = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    n = side * side
+    torch.cuda.set_device(0)
+    ec.init(0)
+    L = ec.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    ec.set_stream(stream)
+    chk = ec._ffi.check
+    if map_u is not None:
+        chk(L.ec_tune_set(b"map_u", map_u))
+
+    def synth(ct, seed, lo=1.0, hi=200.0):
+        b = ec.CellBuffer.empty(n, ct)
+        src = {ec.UInt8: ec.UInt8, ec.UInt16: ec.UInt16, ec.UInt32: ec.UInt32, ec.Float32: ec.Float32, ec.Float64: ec.Float64}.get(ct)
+        if src is not None:
+            chk(L.ec_synth_fill(ct, b.mem.ptr, n, seed, 0, lo, hi, stream))
+        else:  # other integer types: reinterpret a same-width unsigned fill (values stay small and positive)
+            w = {1: ec.UInt8, 2: ec.UInt16, 4: ec.UInt32}.get(SZ[ct])
+            if w is None:  # 8-byte ints: convert from u32
+                t = ec.CellBuffer.empty(n, ec.UInt32)
+                chk(L.ec_synth_fill(ec.UInt32, t.mem.ptr, n, seed, 0, lo, hi, stream))
+                chk(L.ec_convert(ec.UInt32, t.mem.ptr, ct if ct == ec.UInt64 else ec.Int64, b.mem.ptr, n, stream))
+            else:
+                chk(L.ec_synth_fill(w, b.mem.ptr, n, seed, 0, lo, min(hi, 100.0), stream))
+        return b
+
+    def mask(seed):
+        m = ec.Mask.empty(n)
+        chk(L.ec_synth_mask(m.mem.ptr, n, seed, 0, 30, stream))
+        return m
+
+    rows = []
+
+    def bench(name, bytes_per_cell, fn, iters=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        gbs = bytes_per_cell * n / (ms * 1e-3) / 1e9
+        rows.append((name, bytes_per_cell, ms, n / (ms * 1e-3) / 1e9, gbs, gbs / PEAK))
+
+    names = ec.CT_NAMES
+    out64 = ec.CellBuffer.empty(n, ec.Float64)
+    opn = ["Add", "Sub", "Mul", "Div"]
+    # ---- binary arithmetic
+    for lt, rt in [(ec.UInt8, ec.UInt16), (ec.UInt16, ec.UInt16), (ec.Float32, ec.Float32), (ec.Float64, ec.Float32),
+                   (ec.Int64, ec.Float64), (ec.UInt8, ec.UInt8)]:
+        a, b = synth(lt, 1), synth(rt, 2)
+        for op in (ec.ADD, ec.MUL, ec.DIV):
+            bench(f"binop {opn[op]} {names[lt]}∘{names[rt]}→Float64", SZ[lt] + SZ[rt] + 8,
+                  lambda: chk(L.ec_binop(op, lt, a.mem.ptr, rt, b.mem.ptr, n, out64.mem.ptr, stream)))
+        del a, b
+    for lt in (ec.UInt8, ec.Float64):
+        a = synth(lt, 3)
+        v = ec.CellValue(ec.Float64, 2.0).to_ec()
+        bench(f"binop_scalar Mul {names[lt]}∘2.0", SZ[lt] + 8,
+              lambda: chk(L.ec_binop_scalar(ec.MUL, lt, a.mem.ptr, n, C.byref(v), out64.mem.ptr, stream)))
+        del a
+    # ---- masked
+    a, b = synth(ec.Float32, 4, -1000, 1000), synth(ec.Float32, 5, -1000, 1000)
+    ma, mb, mo = mask(11), mask(12), ec.Mask.empty(n)
+    bench("masked_binop Add Float32∘Float32 (+mask AND)", 4 + 4 + 8 + 3,
+          lambda: chk(L.ec_masked_binop(ec.ADD, ec.Float32, a.mem.ptr, ma.mem.ptr, ec.Float32, b.mem.ptr, mb.mem.ptr, n,
+                                        out64.mem.ptr, mo.mem.ptr, stream)))
+    t64 = synth(ec.Float64, 6)
+    bench("masked_binop Mul Float64∘Float32 (+mask AND)", 8 + 4 + 8 + 3,
+          lambda: chk(L.ec_masked_binop(ec.MUL, ec.Float64, t64.mem.ptr, ma.mem.ptr, ec.Float32, b.mem.ptr, mb.mem.ptr, n,
+                                        out64.mem.ptr, mo.mem.ptr, stream)))
+    # ---- masks
+    bench("mask_and", 3, lambda: chk(L.ec_mask_and(ma.mem.ptr, mb.mem.ptr, n, mo.mem.ptr, stream)))
+    bench("mask_not", 2, lambda: chk(L.ec_mask_not(ma.mem.ptr, n, mo.mem.ptr, stream)))
+    cnt = torch.empty(2, dtype=torch.int64, device="cuda")
+    bench("mask_counts", 1, lambda: chk(L.ec_mask_counts_device(ma.mem.ptr, n, cnt.data_ptr(), stream)))
+    nd32 = ec.CellValue(ec.Float32, 3.0).to_ec()
+    bench("mask_from_nodata Float32", 4 + 1, lambda: chk(L.ec_mask_from_nodata(ec.Float32, a.mem.ptr, n, C.byref(nd32), mo.mem.ptr, stream)))
+    o32 = ec.CellBuffer.empty(n, ec.Float32)
+    bench("mask_select Float32", 4 + 1 + 4, lambda: chk(L.ec_mask_select(ec.Float32, a.mem.ptr, ma.mem.ptr, n, C.byref(nd32), o32.mem.ptr, stream)))
+    del t64
+    # ---- unary
+    u16 = synth(ec.UInt16, 7, 0, 65535)
+    nd16 = ec.CellValue(ec.UInt16, 0).to_ec()
+    bench("mask_from_nodata UInt16", 2 + 1, lambda: chk(L.ec_mask_from_nodata(ec.UInt16, u16.mem.ptr, n, C.byref(nd16), mo.mem.ptr, stream)))
+    bench("convert UInt16→Float32", 2 + 4, lambda: chk(L.ec_convert(ec.UInt16, u16.mem.ptr, ec.Float32, o32.mem.ptr, n, stream)))
+    bench("convert UInt16→Float64", 2 + 8, lambda: chk(L.ec_convert(ec.UInt16, u16.mem.ptr, ec.Float64, out64.mem.ptr, n, stream)))
+    bench("convert Float32→Float64", 4 + 8, lambda: chk(L.ec_convert(ec.Float32, a.mem.ptr, ec.Float64, out64.mem.ptr, n, stream)))
+    u8 = synth(ec.UInt8, 8, 0, 255)
+    o16 = ec.CellBuffer.empty(n, ec.Int16)
+    bench("neg UInt8→Int16", 1 + 2, lambda: chk(L.ec_neg(ec.UInt8, u8.mem.ptr, n, o16.mem.ptr, stream)))
+    bench("neg Float32", 4 + 4, lambda: chk(L.ec_neg(ec.Float32, a.mem.ptr, n, o32.mem.ptr, stream)))
+    one = ec.CellValue(ec.Float64, 1.5).to_ec()
+    bench("fill Float64", 8, lambda: chk(L.ec_fill(ec.Float64, out64.mem.ptr, n, C.byref(one), stream)))
+    # ---- min/max
+    keys = torch.empty(2, dtype=torch.int64, device="cuda")
+    f64 = synth(ec.Float64, 9, -1e6, 1e6)
+    for ct, buf in ((ec.UInt8, u8), (ec.UInt16, u16), (ec.Float32, a), (ec.Float64, f64)):
+        bench(f"min_max {names[ct]}", SZ[ct], lambda: chk(L.ec_min_max_keys(ct, buf.mem.ptr, None, n, keys.data_ptr(), stream)))
+    bench("min_max UInt16 masked", 2 + 1, lambda: chk(L.ec_min_max_keys(ec.UInt16, u16.mem.ptr, ma.mem.ptr, n, keys.data_ptr(), stream)))
+    bench("min_max Float32 masked", 4 + 1, lambda: chk(L.ec_min_max_keys(ec.Float32, a.mem.ptr, ma.mem.ptr, n, keys.data_ptr(), stream)))
+
+    print(f"Per-kernel roofline table, {side}x{side} = {n} cells, one MI355X, HIP-event timed, peak {PEAK:.0f} GB/s, map_u={map_u}\n")
+    print("| kernel (through the C ABI) | alg. B/cell | ms/launch | Gcells/s | GB/s | frac of peak |")
+    print("|---|---:|---:|---:|---:|---:|")
+    for name, bpc, ms, gc, gbs, fr in rows:
+        print(f"| {name} | {bpc} | {ms:.4f} | {gc:.1f} | {gbs:.0f} | {fr:.3f} |")
+
+
+if __name__ == "__main__":
+    main()
