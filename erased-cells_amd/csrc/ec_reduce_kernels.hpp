@@ -15,6 +15,8 @@
 // deterministic and needs no zero-initialised memory.
 #pragma once
 
+#include <type_traits>
+
 #include "ec_binop_kernels.hpp"
 
 namespace ecd {
@@ -69,6 +71,55 @@ __device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
     return v;
 }
 
+// ---- 1-byte cells: gfx950 has no packed 8-bit min/max, so four cells of a dword are folded as two
+// packed 16-bit pairs (even bytes / odd bytes, zero- or sign-extended in place): 3 VALU ops to split a
+// dword + v_pk_min/v_pk_max per pair, instead of a per-byte extract/min/max/repack chain.
+template <typename T>
+struct ByteFold {
+    static constexpr bool kSigned = T(-1) < T(0);
+    using H = typename std::conditional<kSigned, int16_t, uint16_t>::type;
+    using H2 = vec<H, 2>;
+    using U2 = vec<uint16_t, 2>;
+    H2 mn_e, mn_o, mx_e, mx_o;  // even-byte and odd-byte accumulators
+
+    __device__ __forceinline__ void init() {
+        const H hi = Limits<T>::hi, lo = Limits<T>::lo;
+        mn_e = mn_o = H2{hi, hi};
+        mx_e = mx_o = H2{lo, lo};
+    }
+    static __device__ __forceinline__ H2 even(uint32_t x) { return __builtin_bit_cast(H2, x << 8) >> 8; }
+    static __device__ __forceinline__ H2 odd(uint32_t x) { return __builtin_bit_cast(H2, x) >> 8; }
+
+    template <bool MASKED>
+    __device__ __forceinline__ void fold(uint32_t x, uint32_t m) {
+        H2 e = even(x), o = odd(x), e_mn = e, e_mx = e, o_mn = o, o_mx = o;
+        if constexpr (MASKED) {
+            // mask bytes are 0/1: widen each to a full 16-bit lane mask, then bit-select the sentinel
+            const uint32_t me = __builtin_bit_cast(uint32_t, __builtin_bit_cast(U2, m & 0x00FF00FFu) * U2{0xFFFF, 0xFFFF});
+            const uint32_t mo = __builtin_bit_cast(uint32_t, __builtin_bit_cast(U2, (m >> 8) & 0x00FF00FFu) * U2{0xFFFF, 0xFFFF});
+            const H hi = Limits<T>::hi, lo = Limits<T>::lo;
+            const uint32_t his = __builtin_bit_cast(uint32_t, H2{hi, hi}), los = __builtin_bit_cast(uint32_t, H2{lo, lo});
+            const uint32_t eb = __builtin_bit_cast(uint32_t, e), ob = __builtin_bit_cast(uint32_t, o);
+            e_mn = __builtin_bit_cast(H2, (eb & me) | (his & ~me));
+            e_mx = __builtin_bit_cast(H2, (eb & me) | (los & ~me));
+            o_mn = __builtin_bit_cast(H2, (ob & mo) | (his & ~mo));
+            o_mx = __builtin_bit_cast(H2, (ob & mo) | (los & ~mo));
+        }
+        mn_e = __builtin_elementwise_min(mn_e, e_mn);
+        mx_e = __builtin_elementwise_max(mx_e, e_mx);
+        mn_o = __builtin_elementwise_min(mn_o, o_mn);
+        mx_o = __builtin_elementwise_max(mx_o, o_mx);
+    }
+    __device__ __forceinline__ T result_min() const {
+        H2 a = __builtin_elementwise_min(mn_e, mn_o);
+        return static_cast<T>(a.x < a.y ? a.x : a.y);
+    }
+    __device__ __forceinline__ T result_max() const {
+        H2 a = __builtin_elementwise_max(mx_e, mx_o);
+        return static_cast<T>(a.x > a.y ? a.x : a.y);
+    }
+};
+
 // partials[2*b] = min key, partials[2*b+1] = max key of block b (int64 order keys).
 template <typename T, bool MASKED, int U>
 __global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict__ p, const uint8_t* __restrict__ mask,
@@ -78,10 +129,13 @@ __global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict
     using TV = vec<T, CPL>;
     using AV = vec<A, CPL>;
     using MV = vec<uint8_t, CPL>;
+    constexpr bool BYTES = sizeof(T) == 1;
     const A hi0 = acc_key<T>(Limits<T>::hi), lo0 = acc_key<T>(Limits<T>::lo);
     AV vmin, vmax;
 #pragma unroll
     for (int k = 0; k < CPL; ++k) { vmin[k] = hi0; vmax[k] = lo0; }
+    ByteFold<typename std::conditional<BYTES, T, uint8_t>::type> bf;
+    bf.init();
 
     const size_t ngroups = n / CPL;
     constexpr size_t TILE = size_t(kBlock) * U;
@@ -90,16 +144,22 @@ __global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict
     const MV* __restrict__ mv = reinterpret_cast<const MV*>(mask);
 
     auto fold = [&](const TV& x, const MV& m) {
+        if constexpr (BYTES) {
+            const u32x4 xw = __builtin_bit_cast(u32x4, x), mw = __builtin_bit_cast(u32x4, m);
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            A key = acc_key<T>(x[k]);
-            A kmin = key, kmax = key;
-            if constexpr (MASKED) {
-                kmin = m[k] ? key : hi0;
-                kmax = m[k] ? key : lo0;
+            for (int k = 0; k < 4; ++k) bf.template fold<MASKED>(xw[k], mw[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                A key = acc_key<T>(x[k]);
+                A kmin = key, kmax = key;
+                if constexpr (MASKED) {
+                    kmin = m[k] ? key : hi0;
+                    kmax = m[k] ? key : lo0;
+                }
+                vmin[k] = kmin < vmin[k] ? kmin : vmin[k];
+                vmax[k] = kmax > vmax[k] ? kmax : vmax[k];
             }
-            vmin[k] = kmin < vmin[k] ? kmin : vmin[k];
-            vmax[k] = kmax > vmax[k] ? kmax : vmax[k];
         }
     };
 
@@ -127,12 +187,17 @@ __global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict
             }
         }
     }
-    // horizontal fold of the lane's CPL accumulators, then the ragged tail cells
+    // horizontal fold of the lane's accumulators, then the ragged tail cells
     A amin = vmin[0], amax = vmax[0];
+    if constexpr (BYTES) {
+        amin = bf.result_min();
+        amax = bf.result_max();
+    } else {
 #pragma unroll
-    for (int k = 1; k < CPL; ++k) {
-        amin = vmin[k] < amin ? vmin[k] : amin;
-        amax = vmax[k] > amax ? vmax[k] : amax;
+        for (int k = 1; k < CPL; ++k) {
+            amin = vmin[k] < amin ? vmin[k] : amin;
+            amax = vmax[k] > amax ? vmax[k] : amax;
+        }
     }
     if (blockIdx.x == 0) {
         for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kBlock) {
