@@ -61,9 +61,17 @@ ec_status check_hip(hipError_t e, const char* what) {
 
 ec_status check_launch(const char* what) { return check_hip(hipGetLastError(), what); }
 
+// HIP's current device is per host thread: bind every calling thread to the library's device once.
+static thread_local int t_bound_device = -1;
+
 static ec_status ensure_init() {
-    if (g_inited) return EC_OK;
-    return set_error(EC_ERR_NOT_INITIALIZED, "ec_init() has not been called (no HIP device bound)");
+    if (!g_inited) return set_error(EC_ERR_NOT_INITIALIZED, "ec_init() has not been called (no HIP device bound)");
+    if (t_bound_device != g_device) {
+        ec_status st = check_hip(hipSetDevice(g_device), "hipSetDevice");
+        if (st != EC_OK) return st;
+        t_bound_device = g_device;
+    }
+    return EC_OK;
 }
 
 ec_status get_scratch(hipStream_t s, Scratch* out) {
@@ -307,6 +315,7 @@ extern "C" ec_status ec_init(int32_t device) {
     g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g_device = device;
     g_inited = true;
+    t_bound_device = device;
     return EC_OK;
 }
 
@@ -531,6 +540,83 @@ extern "C" ec_status ec_min_max(ec_dtype t, const void* p, const uint8_t* mask_o
     st = check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
     if (st != EC_OK) return st;
     return ec_min_max_decode(t, sc.host, mn, mx);
+}
+
+// =================================================================== Ord / Eq
+template <typename W>
+static ec_status first_diff_w(const void* l, const void* r, size_t n, const Scratch& sc, hipStream_t s, unsigned* grid_out) {
+    int cap = g_cus * g_tuning.reduce_bpc;
+    if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
+    const bool al = aligned16(l, r, r);
+    size_t tiles = al ? (n / (16 / sizeof(W)) + size_t(kBlock) * kReduceU - 1) / (size_t(kBlock) * kReduceU) : (n + kBlock - 1) / kBlock;
+    if (tiles < 1) tiles = 1;
+    const unsigned grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
+    k_first_diff_partials<W, kReduceU><<<grid, kBlock, 0, s>>>(static_cast<const W*>(l), static_cast<const W*>(r), n,
+                                                               reinterpret_cast<uint64_t*>(sc.dev), al);
+    *grid_out = grid;
+    return check_launch("first_diff(partials)");
+}
+
+extern "C" ec_status ec_first_difference(ec_dtype t, const void* l, const void* r, size_t n, uint64_t* index, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!ecl::valid(t)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_first_difference: bad dtype %d", int(t));
+    if (!index || (n > 0 && (!l || !r))) return set_error(EC_ERR_ARG, "ec_first_difference: null pointer");
+    *index = n;
+    if (n == 0) return EC_OK;
+    Scratch sc;
+    ec_status st = get_scratch(S(stream), &sc);
+    if (st != EC_OK) return st;
+    unsigned grid = 0;
+    switch (ecl::size_of(t)) {
+        case 1: st = first_diff_w<uint8_t>(l, r, n, sc, S(stream), &grid); break;
+        case 2: st = first_diff_w<uint16_t>(l, r, n, sc, S(stream), &grid); break;
+        case 4: st = first_diff_w<uint32_t>(l, r, n, sc, S(stream), &grid); break;
+        default: st = first_diff_w<uint64_t>(l, r, n, sc, S(stream), &grid); break;
+    }
+    if (st != EC_OK) return st;
+    k_first_diff_finalize<<<1, kBlock, 0, S(stream)>>>(reinterpret_cast<const uint64_t*>(sc.dev), static_cast<int>(grid),
+                                                       reinterpret_cast<uint64_t*>(sc.dev_result()));
+    st = check_launch("first_diff(finalize)");
+    if (st != EC_OK) return st;
+    st = check_hip(hipMemcpyAsync(sc.host, sc.dev_result(), sizeof(uint64_t), hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync");
+    if (st != EC_OK) return st;
+    st = check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+    if (st != EC_OK) return st;
+    const uint64_t first = static_cast<uint64_t>(sc.host[0]);
+    *index = first == ~0ull ? n : first;
+    return EC_OK;
+}
+
+template <typename T>
+static int order_cmp(const void* a, const void* b) {
+    T x, y;
+    std::memcpy(&x, a, sizeof x);
+    std::memcpy(&y, b, sizeof y);
+    const int64_t kx = order_key<T>(x), ky = order_key<T>(y);
+    return (kx > ky) - (kx < ky);
+}
+
+extern "C" ec_status ec_buffer_cmp(ec_dtype lt, const void* l, size_t nl, ec_dtype rt, const void* r, size_t nr,
+                                   int32_t* ordering, ec_stream stream) {
+    EC_REQUIRE_INIT();
+    if (!ordering) return set_error(EC_ERR_ARG, "ec_buffer_cmp: null result pointer");
+    if (!ecl::valid(lt) || !ecl::valid(rt)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_buffer_cmp: bad dtype");
+    if (lt != rt) { *ordering = lt < rt ? -1 : 1; return EC_OK; }  // cell type first (buffer.rs:391-398)
+    const size_t n = nl < nr ? nl : nr;
+    uint64_t idx = n;
+    ec_status st = ec_first_difference(lt, l, r, n, &idx, stream);
+    if (st != EC_OK) return st;
+    if (idx >= n) { *ordering = (nl > nr) - (nl < nr); return EC_OK; }  // common prefix equal: length decides (:416)
+    unsigned char a[8], b[8];
+    const size_t sz = ecl::size_of(lt);
+    st = ec_download(a, static_cast<const char*>(l) + idx * sz, sz, stream);
+    if (st != EC_OK) return st;
+    st = ec_download(b, static_cast<const char*>(r) + idx * sz, sz, stream);
+    if (st != EC_OK) return st;
+#define EC_ROW(ID, T) case ID: *ordering = order_cmp<T>(a, b); return EC_OK;
+    switch (lt) { EC_WITH_CT(EC_ROW) }
+#undef EC_ROW
+    return EC_OK;
 }
 
 // =================================================================== masks

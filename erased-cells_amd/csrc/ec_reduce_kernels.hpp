@@ -279,6 +279,77 @@ __global__ __launch_bounds__(kBlock) void k_min_max_finalize(const int64_t* __re
     }
 }
 
+// ---- first differing cell of two buffers (impl Ord / PartialEq for CellBuffer, src/buffer.rs:373-436).
+// Equality under the reference's total order is bit equality for every cell type, so the scan works
+// on raw cell words of width W; the ordering of the first differing pair is decided by the caller.
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <typename W, int U>
+__global__ __launch_bounds__(kBlock) void k_first_diff_partials(const W* __restrict__ l, const W* __restrict__ r, size_t n,
+                                                                uint64_t* __restrict__ partials, bool aligned) {
+    constexpr int CPL = 16 / sizeof(W);
+    using WV = vec<W, CPL>;
+    uint64_t first = ~0ull;
+    if (aligned) {
+        const size_t ngroups = n / CPL;
+        constexpr size_t TILE = size_t(kBlock) * U;
+        const size_t ntiles = (ngroups + TILE - 1) / TILE;
+        const WV* __restrict__ lv = reinterpret_cast<const WV*>(l);
+        const WV* __restrict__ rv = reinterpret_cast<const WV*>(r);
+        for (size_t tile = blockIdx.x; tile < ntiles && first == ~0ull; tile += gridDim.x) {
+            const size_t base = tile * TILE + threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const size_t g = base + size_t(j) * kBlock;
+                if (g < ngroups) {
+                    const WV a = __builtin_nontemporal_load(lv + g), b = __builtin_nontemporal_load(rv + g);
+#pragma unroll
+                    for (int k = CPL - 1; k >= 0; --k)
+                        if (a[k] != b[k]) { const uint64_t i = g * CPL + k; first = i < first ? i : first; }
+                }
+            }
+        }
+        if (blockIdx.x == 0)
+            for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kBlock)
+                if (l[i] != r[i]) first = i < first ? i : first;
+    } else {
+        const size_t stride = size_t(gridDim.x) * kBlock;
+        for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n && first == ~0ull; i += stride)
+            if (l[i] != r[i]) first = i;
+    }
+    first = wave_min_u64(first);
+    __shared__ uint64_t s_first[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) s_first[wave] = first;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) first = s_first[w] < first ? s_first[w] : first;
+        partials[blockIdx.x] = first;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_first_diff_finalize(const uint64_t* __restrict__ partials, int nparts,
+                                                                uint64_t* __restrict__ result) {
+    uint64_t first = ~0ull;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) first = partials[i] < first ? partials[i] : first;
+    first = wave_min_u64(first);
+    __shared__ uint64_t s_first[kWavesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) s_first[wave] = first;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; ++w) first = s_first[w] < first ? s_first[w] : first;
+        result[0] = first;
+    }
+}
+
 // ---- Mask::counts: bytes are 0/1, so the count of true cells is the byte sum.
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll

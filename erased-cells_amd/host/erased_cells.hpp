@@ -362,21 +362,10 @@ public:
     }
 
     // ---- Ord/Eq (buffer.rs:373-436): cell type first, then lexicographic total order, then length
-    int cmp(const CellBuffer& o) const {
-        if (ct_ != o.ct_) return ct_ < o.ct_ ? -1 : 1;
-        size_t sz = size_of(ct_), n = n_ < o.n_ ? n_ : o.n_;
-        std::vector<unsigned char> a(n_ * sz), b(o.n_ * sz);
-        check(ec_download(a.data(), ptr(), a.size(), current_stream()));
-        check(ec_download(b.data(), o.ptr(), b.size(), current_stream()));
-        for (size_t i = 0; i < n; ++i) {
-            ec_value x{}, y{};
-            x.dtype = y.dtype = static_cast<uint8_t>(ct_);
-            std::memcpy(&x.v, a.data() + i * sz, sz);
-            std::memcpy(&y.v, b.data() + i * sz, sz);
-            int c = CellValue(x).cmp(CellValue(y));
-            if (c) return c;
-        }
-        return (n_ > o.n_) - (n_ < o.n_);
+    int cmp(const CellBuffer& o) const {  // decided on the device: first differing cell, no download
+        int32_t res = 0;
+        check(ec_buffer_cmp(static_cast<ec_dtype>(ct_), ptr(), n_, static_cast<ec_dtype>(o.ct_), o.ptr(), o.n_, &res, current_stream()));
+        return res;
     }
     bool operator==(const CellBuffer& o) const { return cmp(o) == 0; }
     bool operator!=(const CellBuffer& o) const { return cmp(o) != 0; }
@@ -453,7 +442,12 @@ public:
         check(ec_download(b.data(), ptr(), n_, current_stream()));
         return std::vector<bool>(b.begin(), b.end());
     }
-    bool operator==(const Mask& o) const { return n_ == o.n_ && to_vec() == o.to_vec(); }
+    int cmp(const Mask& o) const {  // derived Ord on Vec<bool> (mask.rs:10)
+        int32_t res = 0;
+        check(ec_buffer_cmp(EC_U8, ptr(), n_, EC_U8, o.ptr(), o.n_, &res, current_stream()));
+        return res;
+    }
+    bool operator==(const Mask& o) const { return cmp(o) == 0; }
     bool operator!=(const Mask& o) const { return !(*this == o); }
 
     Mask operator!() const& {  // Not for &Mask (mask.rs:111-116)

@@ -333,17 +333,11 @@ class CellBuffer:
         check(lib().ec_neg(self.ct, self.mem.ptr, self.n, out.mem.ptr, _stream))
         return out
 
-    # ---- Ord / Eq (src/buffer.rs:373-436), host side after download
+    # ---- Ord / Eq (src/buffer.rs:373-436), decided on the device: first differing cell, no download
     def cmp(self, other: "CellBuffer") -> int:
-        if self.ct != other.ct:
-            return (self.ct > other.ct) - (self.ct < other.ct)
-        a, b = _order_keys(self.to_numpy()), _order_keys(other.to_numpy())
-        n = min(a.size, b.size)
-        ne = np.flatnonzero(a[:n] != b[:n])
-        if ne.size:
-            i = int(ne[0])
-            return 1 if a[i] > b[i] else -1
-        return (a.size > b.size) - (a.size < b.size)
+        res = C.c_int32()
+        check(lib().ec_buffer_cmp(self.ct, self.mem.ptr, self.n, other.ct, other.mem.ptr, other.n, C.byref(res), _stream))
+        return res.value
 
     def __eq__(self, other):
         return isinstance(other, CellBuffer) and self.cmp(other) == 0
@@ -358,17 +352,6 @@ class CellBuffer:
 
     def __repr__(self):
         return f"{CT_NAMES[self.ct]}CellBuffer(len={self.n})"
-
-
-def _order_keys(a: np.ndarray) -> np.ndarray:
-    """Total-order keys: ints as themselves, floats per total_cmp (value.rs:260-261)."""
-    if a.dtype.kind != "f":
-        return a
-    it = np.int32 if a.dtype.itemsize == 4 else np.int64
-    ut = np.uint32 if a.dtype.itemsize == 4 else np.uint64
-    b = a.view(it)
-    sh = a.dtype.itemsize * 8 - 1
-    return b ^ ((b >> sh).view(ut) >> ut(1)).view(it)
 
 
 # --------------------------------------------------------------------------- NoData
@@ -496,8 +479,13 @@ class Mask:
         check(lib().ec_mask_or(self.mem.ptr, rhs.mem.ptr, min(self.n, rhs.n), self.mem.ptr, _stream))
         return self
 
+    def cmp(self, other: "Mask") -> int:  # derived Ord on Vec<bool> (mask.rs:10)
+        res = C.c_int32()
+        check(lib().ec_buffer_cmp(UInt8, self.mem.ptr, self.n, UInt8, other.mem.ptr, other.n, C.byref(res), _stream))
+        return res.value
+
     def __eq__(self, other):
-        return isinstance(other, Mask) and self.n == other.n and np.array_equal(self.to_numpy(), other.to_numpy())
+        return isinstance(other, Mask) and self.cmp(other) == 0
 
     __hash__ = None
 

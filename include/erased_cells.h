@@ -155,6 +155,18 @@ ec_status ec_min_max_keys(ec_dtype t, const void *p, const uint8_t *mask_or_null
 ec_status ec_min_max_decode(ec_dtype t, const int64_t keys2_host[2], ec_value *mn, ec_value *mx);
 
 /* ---------------------------------------------------------------- *
+ * Ordering / equality of whole buffers, decided on the device (no download of the cells).
+ * ---------------------------------------------------------------- */
+/* impl Ord / PartialEq for CellBuffer — src/buffer.rs:373-436: cell type first, then the first
+ * differing cell under the total order (total_cmp for floats; equality is bit equality), then
+ * length.  *ordering = -1 / 0 / +1.  Also serves `Mask` (derived Ord on Vec<bool>, mask.rs:10) with
+ * lt == rt == EC_U8.  Synchronous result. */
+ec_status ec_buffer_cmp(ec_dtype lt, const void *l, size_t nl, ec_dtype rt, const void *r, size_t nr,
+                        int32_t *ordering, ec_stream stream);
+/* Index of the first cell whose bits differ in l[0..n) vs r[0..n), or n if none. Synchronous result. */
+ec_status ec_first_difference(ec_dtype t, const void *l, const void *r, size_t n, uint64_t *index, ec_stream stream);
+
+/* ---------------------------------------------------------------- *
  * Masks.
  * ---------------------------------------------------------------- */
 /* MaskedCellBuffer::from_vec_with_nodata — src/masked/masked_buffer.rs:62-71:

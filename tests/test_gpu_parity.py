@@ -268,6 +268,38 @@ def test_masked_binop_fused(ec, variant):
         ec.lib().ec_tune_set(b"binop_variant", 0)
 
 
+# ---------------------------------------------------------------- Ord / Eq on the device: src/buffer.rs:373-436
+@pytest.mark.parametrize("ct", range(NT))
+def test_buffer_cmp_on_device(ec, ct):
+    import ctypes as C
+    n = 300007
+    a = rand_cells(ct, n, 101)
+    da = ec.CellBuffer.from_vec(a)
+    assert da == da and da.cmp(ec.CellBuffer.from_vec(a.copy())) == 0  # NaNs equal themselves bitwise (buffer.rs:624-626)
+    rng = np.random.default_rng(5)
+    for pos in [0, 1, 15, 16, 4095, 4096, n // 2 + 3, n - 1]:
+        b = a.copy()
+        repl = rand_cells(ct, 64, 102 + pos)
+        repl = repl[bits_of(repl) != bits_of(a[pos:pos + 1])[0]]
+        b[pos] = repl[0]
+        if pos + 1000 < n:
+            b[pos + 1000] = repl[-1]  # a later difference must not matter
+        db = ec.CellBuffer.from_vec(b)
+        assert da.cmp(db) == eco.buffer_cmp(a, b), pos
+        assert db.cmp(da) == eco.buffer_cmp(b, a), pos
+        idx = C.c_uint64()
+        ec._ffi.check(ec.lib().ec_first_difference(ct, da.mem.ptr, db.mem.ptr, n, C.byref(idx), None))
+        assert idx.value == pos
+        assert (da == db) is False
+    # prefix relation: shorter sorts first; unaligned windows; cell type decides before content
+    assert da.shard(0, 1000).cmp(da.shard(0, 999)) == 1 and da.shard(0, 999).cmp(da.shard(0, 1000)) == -1
+    assert da.shard(1, 5000).cmp(ec.CellBuffer.from_vec(a[1:5001])) == 0
+    assert da.shard(3, 5000).cmp(ec.CellBuffer.from_vec(a[4:5004])) == eco.buffer_cmp(a[3:5003], a[4:5004])
+    other = ec.CellBuffer.with_defaults(5, (ct + 1) % NT)
+    assert da.cmp(other) == (-1 if ct < (ct + 1) % NT else 1)
+    assert ec.CellBuffer.empty(0, ct).cmp(ec.CellBuffer.empty(0, ct)) == 0
+
+
 def test_synthetic_generators_match_oracle(ec):
     """bench.py's device-side input generator == the oracle's."""
     import ctypes as C
