@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--side", type=int, default=16384, help="raster is side x side cells")
-    ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax"])
+    ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax", "ndvi"])
+    ap.add_argument("--fused", action="store_true", help="masked_chain / ndvi: the single-pass fused kernel instead of the eager chain")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: one side² raster row-sharded over the ranks (default); weak: side² per rank")
     ap.add_argument("--variant", type=int, default=None, help="binop kernel variant: 0 direct, 1 LDS-staged")
@@ -179,12 +180,38 @@ def main():
         out, m2 = ec.CellBuffer.empty(n, ec.Float64), ec.Mask.empty(n)
         bytes_per_cell, kernel = 42, "k_masked_binop<f32,f32,Add> + k_masked_binop<f64,f32,Mul>"
         wl = f"{side}x{side} MaskedCellBuffer f32 (a+b)*c, 30% nodata (BASELINE configs[2], eager)"
+        dt4 = (C.c_uint8 * 4)(ec.Float32, ec.Float32, ec.Float32, 0)
+        p4 = (C.c_void_p * 4)(bufs[0].mem.ptr, bufs[1].mem.ptr, bufs[2].mem.ptr, None)
+        m4 = (C.c_void_p * 4)(masks[0].mem.ptr, masks[1].mem.ptr, masks[2].mem.ptr, None)
+
+        def step_fused():
+            chk(L.ec_masked_fused(ec.ADD, ec.MUL, -1, dt4, p4, m4, n, out.mem.ptr, m2.mem.ptr, stream))
 
         def step():
             chk(L.ec_masked_binop(ec.ADD, ec.Float32, bufs[0].mem.ptr, masks[0].mem.ptr, ec.Float32, bufs[1].mem.ptr,
                                   masks[1].mem.ptr, n, t1.mem.ptr, m1.mem.ptr, stream))
             chk(L.ec_masked_binop(ec.MUL, ec.Float64, t1.mem.ptr, m1.mem.ptr, ec.Float32, bufs[2].mem.ptr,
                                   masks[2].mem.ptr, n, out.mem.ptr, m2.mem.ptr, stream))
+    elif args.workload == "ndvi":
+        nir, red = ec.CellBuffer.empty(n, ec.UInt16), ec.CellBuffer.empty(n, ec.UInt16)
+        chk(L.ec_synth_fill(ec.UInt16, nir.mem.ptr, n, 0x5EED0007, off, 5000.0, 40000.0, stream))
+        chk(L.ec_synth_fill(ec.UInt16, red.mem.ptr, n, 0x5EED0008, off, 5000.0, 30000.0, stream))
+        t1, t2, out = (ec.CellBuffer.empty(n, ec.Float64) for _ in range(3))
+        if args.fused:
+            bytes_per_cell, kernel = 12, "k_fused (nir-red)/(nir+red) u16, one pass"
+            dt4 = (C.c_uint8 * 4)(ec.UInt16, ec.UInt16, ec.UInt16, ec.UInt16)
+            p4 = (C.c_void_p * 4)(nir.mem.ptr, red.mem.ptr, nir.mem.ptr, red.mem.ptr)
+
+            def step():
+                chk(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, n, out.mem.ptr, stream))
+        else:
+            bytes_per_cell, kernel = 48, "k_binop_direct Sub + Add (u16,u16) + Div (f64,f64): eager, 3 passes"
+
+            def step():
+                chk(L.ec_binop(ec.SUB, ec.UInt16, nir.mem.ptr, ec.UInt16, red.mem.ptr, n, t1.mem.ptr, stream))
+                chk(L.ec_binop(ec.ADD, ec.UInt16, nir.mem.ptr, ec.UInt16, red.mem.ptr, n, t2.mem.ptr, stream))
+                chk(L.ec_binop(ec.DIV, ec.Float64, t1.mem.ptr, ec.Float64, t2.mem.ptr, n, out.mem.ptr, stream))
+        wl = f"{side}x{side} u16 NDVI (nir-red)/(nir+red) (BASELINE configs[4] arithmetic at raster scale), " + ("fused" if args.fused else "eager")
     else:
         a = ec.CellBuffer.empty(n, ec.UInt16)
         chk(L.ec_synth_fill(ec.UInt16, a.mem.ptr, n, 0x5EED0006, off, 1.0, 65534.0, stream))
@@ -196,6 +223,11 @@ def main():
             chk(L.ec_min_max_keys(ec.UInt16, a.mem.ptr, None, n, keys.data_ptr(), stream))
             if world > 1:
                 dist.all_reduce(keys, op=dist.ReduceOp.MAX)
+
+    if args.workload == "masked_chain" and args.fused:
+        step = step_fused
+        bytes_per_cell, kernel = 24, "k_fused (a+b)*c f32 + 3 masks, one pass"
+        wl = wl.replace("eager", "fused")
 
     # ---- warm-up, then EXACTLY `steps` timed steps between barrier+synchronize
     for _ in range(args.warmup):

@@ -74,6 +74,8 @@ static ec_status ensure_init() {
     return EC_OK;
 }
 
+ec_status ensure_ready() { return ensure_init(); }
+
 ec_status get_scratch(hipStream_t s, Scratch* out) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_scratch.find(s);

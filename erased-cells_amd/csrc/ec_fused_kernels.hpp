@@ -1,0 +1,231 @@
+// ec_fused_kernels.hpp — fused two-level expression  out = (x o1 y) o2 (z o3 w)  in one pass (gfx950).
+//
+// the reference evaluates operator chains eagerly — `(&nir - &red) / (nir + red)`
+// (src/gdal/rasterband.rs:148,178) is three passes with two f64 temporaries, `(buf + ones) * 2.0`
+// (examples/masked.rs:12) two passes.  Every intermediate of the eager chain is already an f64
+// rounded once per step (src/value.rs:207), so evaluating the same steps in registers gives
+// bit-identical results while the temporaries never touch HBM:
+//   NDVI on u16:      eager 12 + 12 + 24 = 48 B/cell  ->  fused 2 + 2 + 8 = 12 B/cell
+//   (a+b)*c f32+mask: eager 19 + 23 = 42 B/cell       ->  fused 4+4+4 + 8 + 3+1 = 24 B/cell
+//
+// Two kernels: `k_fused_same<T>` when all operands share one cell type (NDVI on u16 bands, the f32
+// chain of config 3): typed loads, all of a tile's loads in flight before the first use; and the
+// generic `k_fused`, where the operand cell types are run-time arguments read through wave-uniform
+// switches (raw load by width class, then conversion by type) — the "run-time typed loaders"
+// alternative to 10^4 template instantiations.  Ops are run-time in both (uniform switch).
+// Aliased operands (z == x, w == y for NDVI) are loaded once.
+#pragma once
+
+#include "ec_binop_kernels.hpp"
+
+namespace ecd {
+
+using D2 = vec<double, 2>;
+
+constexpr int kOpNone = -1;  // o3 == kOpNone: the second term is z alone (three-operand chain)
+
+struct FusedArgs {
+    const void* p[4];        // x, y, z, w (device)
+    const uint8_t* m[4];     // masks or null
+    int8_t dt[4];            // cell types
+    int8_t alias[4];         // alias[k] = j < k if operand k is the same buffer as operand j, else k
+    int8_t o1, o2, o3;
+    int8_t nmask;            // number of distinct masks to AND (0 = unmasked call)
+};
+
+// Operand reads are split in two so that all loads of a pair are in flight before the first use:
+// (1) raw load by WIDTH class only (4 uniform cases, no conversion => no wait inside the branch),
+// (2) conversion of the raw bits by cell TYPE (10 uniform cases, registers only).
+__device__ __forceinline__ u32x4 load_pair_raw(const void* p, int dt, size_t pair) {
+    u32x4 r = {0, 0, 0, 0};
+    switch (dt) {
+        case EC_U8: case EC_I8:
+            r.x = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(p) + pair);
+            break;
+        case EC_U16: case EC_I16:
+            r.x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p) + pair);
+            break;
+        case EC_U32: case EC_I32: case EC_F32: {
+            const vec<uint32_t, 2> v = __builtin_nontemporal_load(reinterpret_cast<const vec<uint32_t, 2>*>(p) + pair);
+            r.x = v.x;
+            r.y = v.y;
+            break;
+        }
+        default:
+            r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + pair);
+            break;
+    }
+    return r;
+}
+
+__device__ __forceinline__ D2 convert_pair(u32x4 r, int dt) {
+    // scalars first: ROCm 7.2's hipcc folded `bit_cast<float>(r.y)` on the vector element to r.x
+    const uint32_t a = r.x, b = r.y, c = r.z, d = r.w;
+    const uint64_t q0 = a | (uint64_t(b) << 32), q1 = c | (uint64_t(d) << 32);
+    double lo, hi;
+    switch (dt) {
+        case EC_U8: lo = double(a & 0xFFu); hi = double((a >> 8) & 0xFFu); break;
+        case EC_I8: lo = double(int8_t(a)); hi = double(int8_t(a >> 8)); break;
+        case EC_U16: lo = double(a & 0xFFFFu); hi = double(a >> 16); break;
+        case EC_I16: lo = double(int16_t(a)); hi = double(int16_t(a >> 16)); break;
+        case EC_U32: lo = double(a); hi = double(b); break;
+        case EC_I32: lo = double(int32_t(a)); hi = double(int32_t(b)); break;
+        case EC_F32: lo = double(__uint_as_float(a)); hi = double(__uint_as_float(b)); break;
+        case EC_U64: lo = double(q0); hi = double(q1); break;
+        case EC_I64: lo = double(int64_t(q0)); hi = double(int64_t(q1)); break;
+        default: lo = __longlong_as_double(static_cast<long long>(q0)); hi = __longlong_as_double(static_cast<long long>(q1)); break;
+    }
+    return D2{lo, hi};
+}
+
+template <typename T>
+__device__ __forceinline__ double load_cell_as(const void* p, size_t i) { return to_f64(static_cast<const T*>(p)[i]); }
+
+__device__ __forceinline__ double load_cell_f64(const void* p, int dt, size_t i) {
+    switch (dt) {
+#define EC_ROW(ID, T) case ID: return load_cell_as<T>(p, i);
+        EC_WITH_CT(EC_ROW)
+#undef EC_ROW
+    }
+    return 0.0;
+}
+
+__device__ __forceinline__ double apply_rt(int op, double a, double b) {
+    switch (op) {  // wave-uniform
+        case EC_ADD: return cell_op<EC_ADD, true>(a, b);
+        case EC_SUB: return cell_op<EC_SUB, true>(a, b);
+        case EC_MUL: return cell_op<EC_MUL, true>(a, b);
+        default: return cell_op<EC_DIV, true>(a, b);
+    }
+}
+
+__device__ __forceinline__ double fused_cell(const FusedArgs& fa, double x, double y, double z, double w) {
+    const double t1 = apply_rt(fa.o1, x, y);
+    const double t2 = fa.o3 == kOpNone ? z : apply_rt(fa.o3, z, w);
+    return apply_rt(fa.o2, t1, t2);
+}
+
+constexpr int kFusedU = 2;
+
+// mask phase: AND of the distinct operand masks (src/masked/masked_buffer.rs:333 applied per step),
+// 16 mask bytes per lane
+__device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* __restrict__ out_mask, size_t n) {
+    if (fa.nmask > 0) {
+        const size_t ngroups = n / 16;
+        const size_t stride = size_t(gridDim.x) * kBlock;
+        u32x4* __restrict__ om = reinterpret_cast<u32x4*>(out_mask);
+        for (size_t g = size_t(blockIdx.x) * kBlock + threadIdx.x; g < ngroups; g += stride) {
+            u32x4 acc = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa.m[0]) + g);
+            for (int k = 1; k < fa.nmask; ++k) acc &= __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa.m[k]) + g);
+            __builtin_nontemporal_store(acc, om + g);
+        }
+        if (blockIdx.x == 0)
+            for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) {
+                uint8_t acc = fa.m[0][i];
+                for (int k = 1; k < fa.nmask; ++k) acc &= fa.m[k][i];
+                out_mask[i] = acc;
+            }
+    }
+}
+
+
+// One workgroup per tile of kBlock*kFusedU pairs, two-front order, as k_binop_direct.
+__global__ __launch_bounds__(kBlock) void k_fused(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
+    const size_t npairs = n >> 1;
+    constexpr size_t TILE = size_t(kBlock) * kFusedU;
+    const size_t tile = two_front_tile();
+    const size_t base = tile * TILE + threadIdx.x;
+    const bool has_w = fa.o3 != kOpNone;
+    D2* __restrict__ op = reinterpret_cast<D2*>(out);
+#pragma unroll
+    for (int j = 0; j < kFusedU; ++j) {
+        const size_t pr = base + size_t(j) * kBlock;
+        if (pr < npairs) {
+            u32x4 raw[4] = {};
+            raw[0] = load_pair_raw(fa.p[0], fa.dt[0], pr);
+            if (fa.alias[1] == 1) raw[1] = load_pair_raw(fa.p[1], fa.dt[1], pr);
+            if (fa.alias[2] == 2) raw[2] = load_pair_raw(fa.p[2], fa.dt[2], pr);
+            if (has_w && fa.alias[3] == 3) raw[3] = load_pair_raw(fa.p[3], fa.dt[3], pr);
+            D2 v[4];
+            v[0] = convert_pair(raw[0], fa.dt[0]);
+            v[1] = fa.alias[1] == 1 ? convert_pair(raw[1], fa.dt[1]) : v[0];
+            v[2] = fa.alias[2] == 2 ? convert_pair(raw[2], fa.dt[2]) : (fa.alias[2] == 0 ? v[0] : v[1]);
+            v[3] = v[2];
+            if (has_w) v[3] = fa.alias[3] == 3 ? convert_pair(raw[3], fa.dt[3]) : (fa.alias[3] == 0 ? v[0] : fa.alias[3] == 1 ? v[1] : v[2]);
+            D2 o;
+            o.x = fused_cell(fa, v[0].x, v[1].x, v[2].x, v[3].x);
+            o.y = fused_cell(fa, v[0].y, v[1].y, v[2].y, v[3].y);
+            __builtin_nontemporal_store(o, op + pr);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const size_t i = n - 1;
+        out[i] = fused_cell(fa, load_cell_f64(fa.p[0], fa.dt[0], i), load_cell_f64(fa.p[1], fa.dt[1], i),
+                            load_cell_f64(fa.p[2], fa.dt[2], i), has_w ? load_cell_f64(fa.p[3], fa.dt[3], i) : 0.0);
+    }
+    fused_mask_phase(fa, out_mask, n);
+}
+
+// All operands of one cell type T (NDVI on u16 bands, the f32 chain of config 3, ...): typed loads,
+// no per-operand dispatch.  Ops stay run-time (uniform switch).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
+    using T2 = vec<T, 2>;
+    const size_t npairs = n >> 1;
+    constexpr size_t TILE = size_t(kBlock) * kFusedU;
+    const size_t tile = two_front_tile();
+    const size_t base = tile * TILE + threadIdx.x;
+    const bool has_w = fa.o3 != kOpNone;
+    D2* __restrict__ op = reinterpret_cast<D2*>(out);
+    const T2* __restrict__ px = static_cast<const T2*>(fa.p[0]);
+    const T2* __restrict__ py = static_cast<const T2*>(fa.p[1]);
+    const T2* __restrict__ pz = static_cast<const T2*>(fa.p[2]);
+    const T2* __restrict__ pw = static_cast<const T2*>(fa.p[3]);
+    T2 x[kFusedU] = {}, y[kFusedU] = {}, z[kFusedU] = {}, w[kFusedU] = {};
+#pragma unroll
+    for (int j = 0; j < kFusedU; ++j) {
+        const size_t pr = base + size_t(j) * kBlock;
+        if (pr < npairs) {
+            x[j] = __builtin_nontemporal_load(px + pr);
+            if (fa.alias[1] == 1) y[j] = __builtin_nontemporal_load(py + pr);
+            if (fa.alias[2] == 2) z[j] = __builtin_nontemporal_load(pz + pr);
+            if (has_w && fa.alias[3] == 3) w[j] = __builtin_nontemporal_load(pw + pr);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kFusedU; ++j) {
+        const size_t pr = base + size_t(j) * kBlock;
+        if (pr < npairs) {
+            const T2 yy = fa.alias[1] == 1 ? y[j] : x[j];
+            const T2 zz = fa.alias[2] == 2 ? z[j] : (fa.alias[2] == 0 ? x[j] : yy);
+            const T2 ww = !has_w ? zz : fa.alias[3] == 3 ? w[j] : (fa.alias[3] == 0 ? x[j] : fa.alias[3] == 1 ? yy : zz);
+            D2 o;
+            o.x = fused_cell(fa, to_f64(x[j].x), to_f64(yy.x), to_f64(zz.x), to_f64(ww.x));
+            o.y = fused_cell(fa, to_f64(x[j].y), to_f64(yy.y), to_f64(zz.y), to_f64(ww.y));
+            __builtin_nontemporal_store(o, op + pr);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const size_t i = n - 1;
+        out[i] = fused_cell(fa, load_cell_as<T>(fa.p[0], i), load_cell_as<T>(fa.p[1], i), load_cell_as<T>(fa.p[2], i),
+                            has_w ? load_cell_as<T>(fa.p[3], i) : 0.0);
+    }
+    fused_mask_phase(fa, out_mask, n);
+}
+
+// Any alignment: one cell per lane.
+__global__ __launch_bounds__(kBlock) void k_fused_cellwise(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
+    const size_t stride = size_t(gridDim.x) * kBlock;
+    const bool has_w = fa.o3 != kOpNone;
+    for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        out[i] = fused_cell(fa, load_cell_f64(fa.p[0], fa.dt[0], i), load_cell_f64(fa.p[1], fa.dt[1], i),
+                            load_cell_f64(fa.p[2], fa.dt[2], i), has_w ? load_cell_f64(fa.p[3], fa.dt[3], i) : 0.0);
+        if (fa.nmask > 0) {
+            uint8_t acc = fa.m[0][i];
+            for (int k = 1; k < fa.nmask; ++k) acc &= fa.m[k][i];
+            out_mask[i] = acc;
+        }
+    }
+}
+
+}  // namespace ecd

@@ -28,6 +28,7 @@ struct Tuning {
 Tuning& tuning();
 int device_cus();
 
+ec_status ensure_ready();  // EC_ERR_NOT_INITIALIZED unless ec_init ran; binds the calling thread to the device
 ec_status set_error(ec_status code, const char* fmt, ...);
 ec_status set_narrowing(int src, int dst);
 ec_status check_launch(const char* what);

@@ -300,6 +300,61 @@ def test_buffer_cmp_on_device(ec, ct):
     assert ec.CellBuffer.empty(0, ct).cmp(ec.CellBuffer.empty(0, ct)) == 0
 
 
+# ---------------------------------------------------------------- fused chains == eager chains
+def test_fused_expression_equals_eager_chain(ec):
+    """(x o1 y) o2 (z o3 w) in one pass is bit-identical to the reference's eager operator chain."""
+    rng = np.random.default_rng(77)
+    for trial in range(40):
+        cts = [int(c) for c in rng.integers(0, NT, size=4)]
+        o1, o2, o3 = (int(o) for o in rng.integers(0, 4, size=3))
+        n = int(rng.choice([1, 2, 3, 511, 512, 513, 1024, 4097, 20001]))
+        h = [rand_cells(ct, n, 200 + trial * 4 + k) for k, ct in enumerate(cts)]
+        d = [ec.CellBuffer.from_vec(a) for a in h]
+        four = trial % 2 == 0
+        if trial % 5 == 0:  # aliased operands, NDVI-shaped
+            h[2], h[3], d[2], d[3] = h[0], h[1], d[0], d[1]
+        got = ec.fused.expr(d[0], o1, d[1], o2, d[2], o3 if four else ec.fused.OP_NONE, d[3] if four else None)
+        t1 = d[0]._binop(o1, d[1])
+        t2 = d[2]._binop(o3, d[3]) if four else d[2]
+        exp = t1._binop(o2, t2)
+        assert got.cell_type() == ec.Float64 and got.len() == n
+        assert np.array_equal(bits_of(got.to_numpy()), bits_of(exp.to_numpy())), (trial, cts, (o1, o2, o3), n)
+        # and against the oracle (both-NaN commutative cells by class, as for the eager ops)
+        e1 = eco.f_binop(o1, h[0], h[1])
+        e2 = eco.f_binop(o3, h[2], h[3]) if four else h[2]
+        eo = eco.f_binop(o2, e1, e2)
+        assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=np.isnan(eo))
+    # unaligned windows take the cell-wise kernel
+    a, b = rand_cells(eco.U16, 5000, 301), rand_cells(eco.U16, 5000, 302)
+    da, db = ec.CellBuffer.from_vec(a).shard(1, 4000), ec.CellBuffer.from_vec(b).shard(3, 4000)
+    got = ec.fused.ndvi(da, db)
+    exp = (da - db) / (da + db)
+    assert np.array_equal(bits_of(got.to_numpy()), bits_of(exp.to_numpy()))
+    assert ec.fused.ndvi(da.shard(0, 0), db).cell_type() == ec.UInt8  # empty chain -> UInt8 (buffer.rs:233-234)
+    # zip truncation of every step
+    assert ec.fused.add_mul(da, db.shard(0, 100), da).len() == 100
+
+
+def test_fused_masked_expression_equals_eager_chain(ec):
+    for n in (1, 17, 4096, 50001):
+        cells = [rand_cells(ct, n, 400 + k) for k, ct in enumerate((eco.F32, eco.F32, eco.F32, eco.U16))]
+        masks = [rand_mask(n, 410 + k) for k in range(4)]
+        m = [ec.MaskedCellBuffer(ec.CellBuffer.from_vec(c), ec.Mask.new(k)) for c, k in zip(cells, masks)]
+        got = ec.fused.add_mul(m[0], m[1], m[2])  # BASELINE config 3
+        exp = (m[0] + m[1]) * m[2]
+        assert np.array_equal(bits_of(got.buffer().to_numpy()), bits_of(exp.buffer().to_numpy()))
+        assert np.array_equal(got.mask().to_numpy(), masks[0] & masks[1] & masks[2])
+        got = ec.fused.expr(m[0], ec.SUB, m[3], ec.DIV, m[1], ec.MUL, m[2])
+        exp = (m[0] - m[3]) / (m[1] * m[2])
+        assert np.array_equal(bits_of(got.buffer().to_numpy()), bits_of(exp.buffer().to_numpy()))
+        assert np.array_equal(got.mask().to_numpy(), masks[0] & masks[1] & masks[2] & masks[3])
+        got = ec.fused.ndvi(m[3], m[0])  # aliased operands: each mask ANDed once
+        exp = (m[3] - m[0]) / (m[3] + m[0])
+        assert np.array_equal(bits_of(got.buffer().to_numpy()), bits_of(exp.buffer().to_numpy()))
+        assert np.array_equal(got.mask().to_numpy(), exp.mask().to_numpy())
+        assert got.counts() == exp.counts()
+
+
 def test_synthetic_generators_match_oracle(ec):
     """bench.py's device-side input generator == the oracle's."""
     import ctypes as C

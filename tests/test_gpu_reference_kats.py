@@ -274,6 +274,24 @@ def test_read_cells_ndvi(ec, golden_dir):
     assert float(mn.value).hex() == NDVI_MIN_HEX and float(mx.value).hex() == NDVI_MAX_HEX
 
 
+def test_ndvi_fused_single_pass(ec, golden_dir):
+    """The same two GDAL tests through the fused single-pass kernel: identical bits."""
+    red_c, red_nd = _band(golden_dir, "B4")
+    nir_c, nir_nd = _band(golden_dir, "B5-nd")
+    red, nir = ec.CellBuffer.from_vec(red_c.ravel()), ec.CellBuffer.from_vec(_band(golden_dir, "B5")[0].ravel())
+    ndvi = ec.fused.ndvi(nir, red)
+    assert ndvi == (nir - red) / (nir + red)
+    mn, mx = ndvi.min_max()
+    assert float(mn.value).hex() == NDVI_MIN_HEX and float(mx.value).hex() == NDVI_MAX_HEX
+    mred = ec.MaskedCellBuffer.from_vec_with_nodata(red_c.ravel(), ec.NoData.new(np.uint16(red_nd)))
+    mnir = ec.MaskedCellBuffer.from_vec_with_nodata(nir_c.ravel(), ec.NoData.new(np.uint16(nir_nd)))
+    m = ec.fused.ndvi(mnir, mred)
+    assert m == (mnir - mred) / (mnir + mred)
+    assert m.counts() == (31430, 4)
+    mn, mx = m.min_max()
+    assert float(mn.value).hex() == NDVI_MIN_HEX and float(mx.value).hex() == NDVI_MAX_HEX
+
+
 def test_read_cells_masked_ndvi_sharded(ec, golden_dir):
     """src/gdal/rasterband.rs:166-191 (B.26, B.27) — and BASELINE config 5: convert u16->f32,
     NDVI, rows sharded 8 ways (22,21,...,21), shard results combined through the min/max keys."""
