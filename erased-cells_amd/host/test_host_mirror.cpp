@@ -11,6 +11,7 @@
 #include <limits>
 
 #include "erased_cells.hpp"
+#include "raster_io.hpp"
 
 using namespace erased_cells;
 
@@ -318,8 +319,60 @@ static void masked_tests() {
     }
 }
 
+// ------------------------------------------------------------------ src/gdal/rasterband.rs:20-36, 57-71, 138-191; src/gdal/mod.rs:49-70
+static void gdal_tests(const std::string& data_dir) {
+    auto path = [&](const char* name) { return data_dir + "/" + name; };
+    {  // doc-test read_cells: buffer.min_max() equals the band's min/max
+        RasterBand rb = RasterBand::open(path("L8-Elkton-VA-B5.tiff"));
+        CHECK(rb.size() == std::make_pair(size_t(186), size_t(169)) && rb.band_type() == CellType::UInt16);
+        auto [mn, mx] = rb.read_cells().min_max();
+        CHECK(mn == CellValue(uint16_t(5469)) && mx == CellValue(uint16_t(39368)) && mn.cell_type() == CellType::UInt16);
+    }
+    {  // read_cells: NDVI against the gdal_calc numbers quoted in the reference
+        CellBuffer red = RasterBand::open(path("L8-Elkton-VA-B4.tiff")).read_cells();
+        CellBuffer nir = RasterBand::open(path("L8-Elkton-VA-B5.tiff")).read_cells();
+        CellBuffer ndvi = (nir - red) / (nir + red);
+        auto [mn, mx] = ndvi.min_max();
+        CHECK(mn.to_f64() - -0.1248899911993 < 1e-8 && std::fabs(mn.to_f64() - -0.1248899911993) < 1e-8);
+        CHECK(mx.to_f64() - 0.66998345719859 < 1e-8 && std::fabs(mx.to_f64() - 0.66998345719859) < 1e-8);
+        CHECK(mn.to_f64() == -0x1.ff8ca5bcc77dcp-4 && mx.to_f64() == 0x1.5708125b0ed28p-1);
+    }
+    {  // read_cells_masked: the NIR band has 4 nodata cells, as has the result
+        RasterBand nir_rb = RasterBand::open(path("L8-Elkton-VA-B5-nd.tiff"));
+        CHECK(nir_rb.no_data_value().has_value() && *nir_rb.no_data_value() == 0.0);
+        MaskedCellBuffer red = RasterBand::open(path("L8-Elkton-VA-B4.tiff")).read_cells_masked();
+        MaskedCellBuffer nir = nir_rb.read_cells_masked();
+        auto [nir_data, nir_nodata] = nir.counts();
+        CHECK(nir_data + nir_nodata == 186 * 169 && nir_nodata == 4);
+        MaskedCellBuffer ndvi = (nir - red) / (nir + red);
+        CHECK(ndvi.counts() == std::make_pair(nir_data, nir_nodata));
+        auto [mn, mx] = ndvi.min_max();
+        CHECK(mn.to_f64() == -0x1.ff8ca5bcc77dcp-4 && mx.to_f64() == 0x1.5708125b0ed28p-1);
+        // row-block ingest: 8 shards (22,21,...,21 rows) tile the band
+        size_t rows = 169, row0 = 0, total_nodata = 0;
+        for (size_t g = 0; g < 8; ++g) {
+            uint64_t off = 0, len = 0;
+            check(ec_shard_range(rows, 186, static_cast<uint32_t>(g), 8, &off, &len));
+            CHECK(off == row0 * 186);
+            MaskedCellBuffer part = nir_rb.read_cells_masked_rows(row0, len / 186);
+            total_nodata += part.counts().second;
+            row0 += len / 186;
+        }
+        CHECK(row0 == rows && total_nodata == 4);
+    }
+    // GdalND -> NoData<T> (src/gdal/mod.rs:49-70): range-checked
+    CHECK(!nodata_from_f64<uint16_t>(std::nullopt, "u16").value().has_value());
+    CHECK(nodata_from_f64<uint16_t>(0.0, "u16").value() == uint16_t(0));
+    CHECK(nodata_from_f64<uint8_t>(255.9, "u8").value() == uint8_t(255));
+    CHECK(nodata_from_f64<float>(-9999.0, "f32").value() == -9999.0f);
+    CHECK_THROWS(NoDataConversionError, nodata_from_f64<uint8_t>(-9999.0, "u8"));
+    CHECK_THROWS(NoDataConversionError, nodata_from_f64<int16_t>(std::nan(""), "i16"));
+    CHECK_THROWS(Error, RasterBand::open(path("does-not-exist.tiff")));
+}
+
 int main(int argc, char** argv) {
     bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
+    const char* dd = std::getenv("TEST_DATA_DIR");  // as the reference's testkit (.cargo/config.toml:3)
     try {
         ctype_tests();
         value_tests();
@@ -330,6 +383,7 @@ int main(int argc, char** argv) {
             buffer_tests();
             mask_tests();
             masked_tests();
+            if (dd) gdal_tests(dd);
         } else {
             nodata_tests();
         }
@@ -337,6 +391,7 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "FAILED with exception: %s\n", e.what());
         return 1;
     }
-    std::printf("host mirror: %d checks passed%s\n", g_checks, host_only ? " (host-only subset)" : "");
+    std::printf("host mirror: %d checks passed%s%s\n", g_checks, host_only ? " (host-only subset)" : "",
+                (!host_only && dd) ? " (incl. GDAL fixture tests)" : "");
     return 0;
 }

@@ -4,7 +4,7 @@
 `buffer`   host mirror of CellBuffer / MaskedCellBuffer / Mask / NoData / CellValue
 `sharded`  row-block sharding across ranks + the RCCL all-reduce for min/max and counts
 """
-from . import _ffi, fused
+from . import _ffi, fused, raster
 from ._ffi import EcError, NarrowingError, build, lib
 from .buffer import (ADD, CELL_TYPES, CT_NAMES, DIV, MUL, NP_DTYPES, SUB, CellBuffer, CellValue, DeviceMem,
                      Float32, Float64, Int8, Int16, Int32, Int64, Mask, MaskedCellBuffer, NoData, UInt8,

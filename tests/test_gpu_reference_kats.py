@@ -274,6 +274,31 @@ def test_read_cells_ndvi(ec, golden_dir):
     assert float(mn.value).hex() == NDVI_MIN_HEX and float(mx.value).hex() == NDVI_MAX_HEX
 
 
+def test_raster_ingest_mirror(ec, golden_dir):
+    """RasterBandEx mirror (src/gdal/rasterband.rs:82-125, src/gdal/mod.rs:49-70): read_cells / read_cells_masked,
+    nodata f64 -> NoData<T> range check, row-block reads that tile the band."""
+    from erased_cells_hip import raster, sharded
+    rb = raster.RasterBand.open(os.path.join(golden_dir, "L8-Elkton-VA-B5-nd.tiff"))
+    assert rb.size() == (186, 169) and rb.band_type() == ec.UInt16 and rb.no_data_value() == 0.0
+    m = rb.read_cells_masked()
+    assert m.counts() == (31430, 4) and m.cell_type() == ec.UInt16
+    assert rb.read_cells().min_max() == (ec.CellValue(ec.UInt16, 0), ec.CellValue(ec.UInt16, 39368))
+    nodata = 0
+    for g in range(8):
+        off, ln = sharded.shard_range(169, 186, g, 8)
+        part = rb.read_cells_masked_rows(off // 186, ln // 186)
+        assert part.buffer() == m.buffer().shard(off, ln)
+        nodata += part.counts()[1]
+    assert nodata == 4
+    assert raster.nodata_from_f64(ec.UInt8, 255.9).value(ec.UInt8).value == 255
+    assert raster.nodata_from_f64(ec.Float32, -9999.0).value(ec.Float32).value == np.float32(-9999.0)
+    assert raster.nodata_from_f64(ec.Int16, None).value(ec.Int16) is None
+    with pytest.raises(raster.NoDataConversionError):
+        raster.nodata_from_f64(ec.UInt8, -9999.0)
+    with pytest.raises(raster.NoDataConversionError):
+        raster.nodata_from_f64(ec.Int16, float("nan"))
+
+
 def test_ndvi_fused_single_pass(ec, golden_dir):
     """The same two GDAL tests through the fused single-pass kernel: identical bits."""
     red_c, red_nd = _band(golden_dir, "B4")

@@ -25,6 +25,8 @@ def test_host_mirror_lattice_and_scalars_no_gpu():
 def test_host_mirror_reference_tests_on_gpu():
     if not os.path.exists(BIN):
         _build()
-    r = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, TEST_DATA_DIR=os.path.join(ROOT, "tests", "golden"))  # the reference's fixtures
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "checks passed" in r.stdout and "host-only" not in r.stdout
+    assert "incl. GDAL fixture tests" in r.stdout
