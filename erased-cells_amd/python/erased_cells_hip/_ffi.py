@@ -70,6 +70,8 @@ SIGNATURES = {
     "ec_min_max": (I32, [C.c_uint8, VP, U8P, SZ, PV, PV, VP]),
     "ec_min_max_keys": (I32, [C.c_uint8, VP, U8P, SZ, VP, VP]),
     "ec_min_max_decode": (I32, [C.c_uint8, C.POINTER(C.c_int64), PV, PV]),
+    "ec_allreduce_min_max_keys": (I32, [VP, VP, VP]),
+    "ec_allreduce_counts": (I32, [VP, VP, VP]),
     "ec_buffer_cmp": (I32, [C.c_uint8, VP, SZ, C.c_uint8, VP, SZ, C.POINTER(I32), VP]),
     "ec_first_difference": (I32, [C.c_uint8, VP, VP, SZ, C.POINTER(C.c_uint64), VP]),
     "ec_mask_from_nodata": (I32, [C.c_uint8, VP, SZ, PV, U8P, VP]),

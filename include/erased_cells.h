@@ -169,6 +169,14 @@ ec_status ec_min_max_keys(ec_dtype t, const void *p, const uint8_t *mask_or_null
                           int64_t *keys2_dev, ec_stream stream);
 ec_status ec_min_max_decode(ec_dtype t, const int64_t keys2_host[2], ec_value *mn, ec_value *mx);
 
+/* The sharded path's only exchange, for hosts that own an RCCL communicator (`ncclComm_t`, one rank per
+ * GPU): in-place all-reduce over xGMI of the 16-byte device payloads written by
+ * ec_min_max_keys (MAX over two int64) and ec_mask_counts_device (SUM over two uint64).  Asynchronous on
+ * `stream`.  librccl is loaded lazily; EC_ERR_RCCL if it is missing or the collective fails.
+ * (bench.py and the Python mirror use torch.distributed's all_reduce, which is the same RCCL call.) */
+ec_status ec_allreduce_min_max_keys(void *rccl_comm, int64_t *keys2_dev, ec_stream stream);
+ec_status ec_allreduce_counts(void *rccl_comm, uint64_t *counts2_dev, ec_stream stream);
+
 /* ---------------------------------------------------------------- *
  * Ordering / equality of whole buffers, decided on the device (no download of the cells).
  * ---------------------------------------------------------------- */

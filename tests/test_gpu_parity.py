@@ -355,6 +355,50 @@ def test_fused_masked_expression_equals_eager_chain(ec):
         assert got.counts() == exp.counts()
 
 
+@pytest.mark.timeout(300)
+def test_native_rccl_allreduce_of_reduction_payloads(ec):
+    """ec_allreduce_min_max_keys / ec_allreduce_counts drive RCCL directly (no torch): a 1-rank
+    communicator on this GPU must leave the payloads unchanged and decode to the oracle's answer."""
+    import ctypes as C
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so.1")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        L = ec.lib()
+        a = rand_cells(eco.F32, 200001, 501)
+        m = rand_mask(200001, 502)
+        d, dm = ec.CellBuffer.from_vec(a), ec.Mask.new(m)
+        keys, counts = ec.DeviceMem(16), ec.DeviceMem(16)
+        ec._ffi.check(L.ec_min_max_keys(ec.Float32, d.mem.ptr, dm.mem.ptr, d.len(), keys.ptr, None))
+        ec._ffi.check(L.ec_allreduce_min_max_keys(comm, keys.ptr, None))
+        ec._ffi.check(L.ec_mask_counts_device(dm.mem.ptr, dm.len(), counts.ptr, None))
+        ec._ffi.check(L.ec_allreduce_counts(comm, counts.ptr, None))
+        k, c = np.empty(2, np.int64), np.empty(2, np.uint64)
+        ec._ffi.check(L.ec_download(k.ctypes.data_as(C.c_void_p), keys.ptr, 16, None))
+        ec._ffi.check(L.ec_download(c.ctypes.data_as(C.c_void_p), counts.ptr, 16, None))
+        from erased_cells_hip import sharded
+        mn, mx = sharded.combine_min_max_keys(ec.Float32, (int(k[0]), int(k[1])))
+        emn, emx = eco.f_min_max(a, m)
+        assert (mn.bits(), mx.bits()) == (emn.bits(), emx.bits())
+        assert (int(c[0]), int(c[1])) == eco.mask_counts(m)
+        assert L.ec_allreduce_min_max_keys(None, keys.ptr, None) == ec._ffi.EC_ERR_ARG
+    finally:
+        rccl.ncclCommDestroy(comm)
+
+
 def test_synthetic_generators_match_oracle(ec):
     """bench.py's device-side input generator == the oracle's."""
     import ctypes as C

@@ -1,0 +1,248 @@
+// tune_binop4.hip — fourth A/B round: randomized order, more rounds, tile-order permutations.
+// tune_binop2.hip — second A/B round for the u8 ÷ u16 -> f64 kernel (dev tool):
+// store cache policies, load policies, workgroup size, wave-contiguous vs
+// block-interleaved tiles, tile depth.  One block per tile (the launch shape
+// round 1 found fastest).  Experimental kernel local to this file; whatever
+// wins is promoted into ec_binop_kernels.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "ec_binop_kernels.hpp"
+
+#define CK(x)                                                                                      \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                               \
+        }                                                                                          \
+    } while (0)
+
+using namespace ecd;
+using D2 = vec<double, 2>;
+
+// experimental: divide for operands that cannot over/underflow (integers): no v_div_scale / v_div_fmas
+__device__ __forceinline__ double int_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = a * r;
+    double rem = __builtin_fma(-b, q, a);
+    q = __builtin_fma(rem, r, q);
+    q = __builtin_amdgcn_div_fixup(q, b, a);
+    return (q != q) ? bits_f64(kNegQNaN) : q;
+}
+
+
+// store policies: 0 plain, 1 nt (builtin), 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 sc0, 6 nt sc0 sc1
+template <int POL>
+__device__ __forceinline__ void store16(D2* p, D2 v) {
+    if constexpr (POL == 0) *p = v;
+    else if constexpr (POL == 1) __builtin_nontemporal_store(v, p);
+    else if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr (POL == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr (POL == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr (POL == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int U, int BLOCK, bool WAVE_CONTIG, int STPOL, bool NTL, int OP, int LDSKB = 0, int SLEEP = 0, int PERM = 0>
+__global__ __launch_bounds__(BLOCK) void k_exp(const uint8_t* __restrict__ l, const uint16_t* __restrict__ r,
+                                               double* __restrict__ out, size_t n) {
+    using L2 = vec<uint8_t, 2>;
+    using R2 = vec<uint16_t, 2>;
+    if constexpr (LDSKB > 0) {  // occupancy cap: reserve LDS so fewer workgroups fit per CU
+        __shared__ volatile uint32_t pad[LDSKB * 256];
+        if (threadIdx.x == 0) pad[0] = 1;
+    }
+    const size_t npairs = n >> 1;
+    constexpr size_t TILE = size_t(BLOCK) * U;
+    size_t tile = blockIdx.x;  // one block per tile; host guarantees npairs % TILE == 0
+    if constexpr (PERM == 1) {  // XCD-contiguous: blocks b, b+8, ... (same XCD) walk one contiguous eighth of the raster
+        const size_t per = gridDim.x / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    } else if constexpr (PERM == 2) {  // two fronts: even blocks from the start, odd blocks from the end
+        tile = (blockIdx.x & 1) ? gridDim.x - 1 - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+    }
+    size_t base, stride;
+    if constexpr (WAVE_CONTIG) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        base = tile * TILE + size_t(wave) * (64 * U) + lane;
+        stride = 64;
+    } else {
+        base = tile * TILE + threadIdx.x;
+        stride = BLOCK;
+    }
+    if (base + (U - 1) * stride >= npairs) return;
+    const L2* lp = reinterpret_cast<const L2*>(l);
+    const R2* rp = reinterpret_cast<const R2*>(r);
+    D2* op = reinterpret_cast<D2*>(out);
+    L2 a[U];
+    R2 b[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        a[j] = load_vec<NTL>(lp + base + j * stride);
+        b[j] = load_vec<NTL>(rp + base + j * stride);
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        D2 o;
+        if constexpr (OP == 7) {
+            o.x = int_div(to_f64(a[j].x), to_f64(b[j].x));
+            o.y = int_div(to_f64(a[j].y), to_f64(b[j].y));
+        } else {
+            o.x = cell_op<OP, false>(to_f64(a[j].x), to_f64(b[j].x));
+            o.y = cell_op<OP, false>(to_f64(a[j].y), to_f64(b[j].y));
+        }
+        store16<STPOL>(op + base + j * stride, o);
+        if constexpr (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+    }
+}
+
+__global__ void k_fill(uint8_t* a, uint16_t* b, size_t n) {
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        a[i] = uint8_t(splitmix64(0x5EED0001ull ^ i) % 256);
+        b[i] = uint16_t(1 + splitmix64(0x5EED0002ull ^ i) % 65535);
+    }
+}
+
+__global__ void k_checksum(const uint64_t* p, size_t n, unsigned long long* acc) {
+    size_t stride = size_t(gridDim.x) * blockDim.x;
+    unsigned long long s = 0;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) s += p[i] * (i | 1);
+    atomicAdd(acc, s);
+}
+
+// pure-memory references, one block per 256*U*16 B tile
+template <int U>
+__global__ __launch_bounds__(256) void k_copy_tile(const u32x4* __restrict__ s, u32x4* __restrict__ d) {
+    size_t base = size_t(blockIdx.x) * 256 * U + threadIdx.x;
+    u32x4 x[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) x[j] = s[base + j * 256];
+#pragma unroll
+    for (int j = 0; j < U; ++j) d[base + j * 256] = x[j];
+}
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_write_tile(u32x4* __restrict__ d) {
+    size_t base = size_t(blockIdx.x) * 256 * U + threadIdx.x;
+    u32x4 v = {1, 2, 3, 4};
+#pragma unroll
+    for (int j = 0; j < U; ++j) store_vec<NT>(d + base + j * 256, v);
+}
+template <int U>
+__global__ __launch_bounds__(256) void k_read_tile(const u32x4* __restrict__ s, uint32_t* sink) {
+    size_t base = size_t(blockIdx.x) * 256 * U + threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < U; ++j) acc ^= s[base + j * 256];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345) *sink = 1;
+}
+
+struct Variant {
+    std::string name;
+    std::function<void()> launch;
+    double bytes;
+    std::vector<float> ms;
+};
+
+int main(int argc, char** argv) {
+    size_t side = argc > 1 ? strtoull(argv[1], 0, 10) : 16384;
+    int rounds = argc > 2 ? atoi(argv[2]) : 5;
+    int iters = argc > 3 ? atoi(argv[3]) : 10;
+    const size_t n = side * side;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s  CUs %d  n %zu cells\n", prop.gcnArchName, prop.multiProcessorCount, n);
+    uint8_t* a;
+    uint16_t* b;
+    double* out;
+    unsigned long long* acc;
+    uint32_t* sink;
+    CK(hipMalloc(&a, n));
+    CK(hipMalloc(&b, n * 2));
+    CK(hipMalloc(&out, n * 8));
+    CK(hipMalloc(&acc, 8));
+    CK(hipMalloc(&sink, 4));
+    k_fill<<<2048, 256>>>(a, b, n);
+    CK(hipDeviceSynchronize());
+
+    std::vector<Variant> vs;
+    const double b11 = 11.0 * double(n);
+    auto add = [&](std::string name, double bytes, std::function<void()> f) { vs.push_back(Variant{name, f, bytes, {}}); };
+
+#define EXP(U, BLOCK, WC, STPOL, NTL, OPV, OPN)                                                               \
+    if ((n / 2) % (size_t(BLOCK) * U) == 0)                                                                  \
+        add(std::string("exp ") + OPN + " U" #U " blk" #BLOCK " wc" #WC " st" #STPOL " ntl" #NTL, b11, [=]() {   \
+            k_exp<U, BLOCK, WC, STPOL, NTL, OPV><<<unsigned((n / 2) / (size_t(BLOCK) * U)), BLOCK>>>(a, b, out, n); \
+        })
+
+    add("ref copy_tile U8 (4B rd + 4B wr per cell)", 8.0 * n, [=]() { k_copy_tile<8><<<unsigned(n / 4 / (256 * 8)), 256>>>((const u32x4*)out, (u32x4*)out + n / 4); });
+    add("ref write_tile U8 plain (8B/cell)", 8.0 * n, [=]() { k_write_tile<8, false><<<unsigned(n / 2 / (256 * 8)), 256>>>((u32x4*)out); });
+    add("ref write_tile U8 nt (8B/cell)", 8.0 * n, [=]() { k_write_tile<8, true><<<unsigned(n / 2 / (256 * 8)), 256>>>((u32x4*)out); });
+    add("ref read_tile U8 (8B/cell)", 8.0 * n, [=]() { k_read_tile<8><<<unsigned(n / 2 / (256 * 8)), 256>>>((const u32x4*)out, sink); });
+
+#define EXPX(U, BLOCK, STPOL, NTL, OPV, OPN, LDSKB, SLEEP, PERM)                                             \
+    if ((n / 2) % (size_t(BLOCK) * U) == 0 && ((n / 2) / (size_t(BLOCK) * U)) % 8 == 0)                      \
+        add(std::string("exp ") + OPN + " U" #U " blk" #BLOCK " ntl" #NTL " lds" #LDSKB "KB sleep" #SLEEP " perm" #PERM, b11, [=]() { \
+            k_exp<U, BLOCK, false, STPOL, NTL, OPV, LDSKB, SLEEP, PERM><<<unsigned((n / 2) / (size_t(BLOCK) * U)), BLOCK>>>(a, b, out, n); \
+        })
+    EXPX(2, 256, 1, true, EC_DIV, "div", 0, 0, 2);
+    EXPX(2, 256, 1, true, 7, "intdiv", 0, 0, 2);
+    EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 2);
+    EXPX(2, 512, 1, true, EC_DIV, "div", 0, 0, 2);
+    EXPX(2, 512, 1, true, 7, "intdiv", 0, 0, 2);
+    EXPX(4, 256, 1, true, 7, "intdiv", 0, 0, 2);
+    add("LIB k_binop_direct div U2 nt/nt (library kernel, same buffers)", b11, [=]() {
+        k_binop_direct<uint8_t, uint16_t, EC_DIV, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a, b, out, n); });
+    add("LIB k_binop_direct add U2 nt/nt (library kernel, same buffers)", b11, [=]() {
+        k_binop_direct<uint8_t, uint16_t, EC_ADD, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a, b, out, n); });
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<unsigned long long> sums(vs.size(), 0);
+    unsigned long long rng = 12345;
+    for (int round = -1; round < rounds; ++round) {
+        std::vector<size_t> order(vs.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        if (round >= 0) { for (size_t i = order.size(); i > 1; --i) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; std::swap(order[i - 1], order[(rng >> 33) % i]); } }
+        for (size_t oi = 0; oi < order.size(); ++oi) {
+            size_t vi = order[oi];
+            Variant& v = vs[vi];
+            if (round < 0) {
+                CK(hipMemset(out, 0xEE, 64));
+                v.launch();
+                CK(hipGetLastError());
+                CK(hipMemset(acc, 0, 8));
+                k_checksum<<<2048, 256>>>((const uint64_t*)out, n, acc);
+                CK(hipMemcpy(&sums[vi], acc, 8, hipMemcpyDeviceToHost));
+                continue;
+            }
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) v.launch();
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            v.ms.push_back(ms / iters);
+        }
+    }
+    printf("%-52s %9s %9s %9s %9s %8s  %s\n", "variant", "med_ms", "min_ms", "max_ms", "GB/s", "%of8TB", "checksum");
+    for (size_t vi = 0; vi < vs.size(); ++vi) {
+        Variant& v = vs[vi];
+        std::sort(v.ms.begin(), v.ms.end());
+        float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
+        double gbs = v.bytes / (med * 1e-3) / 1e9;
+        printf("%-52s %9.4f %9.4f %9.4f %9.1f %7.1f%%  %016llx\n", v.name.c_str(), med, mn, v.ms.back(), gbs, gbs / 80.0, sums[vi]);
+    }
+    return 0;
+}
