@@ -1,8 +1,15 @@
-// tune_binop2.hip — second A/B round for the u8 ÷ u16 -> f64 kernel (dev tool):
-// store cache policies, load policies, workgroup size, wave-contiguous vs
-// block-interleaved tiles, tile depth.  One block per tile (the launch shape
-// round 1 found fastest).  Experimental kernel local to this file; whatever
-// wins is promoted into ec_binop_kernels.hpp.
+// tune_binop.hip — A/B harness for the u8 ÷ u16 -> f64 kernel shape (dev tool, not part of the library).
+//
+// One experimental kernel (k_exp) with every knob that was swept in round 1 — tile depth U, workgroup
+// size, store cache policy, non-temporal loads, occupancy cap (LDS reservation), store pacing
+// (s_sleep), workgroup->tile order (single front / XCD-contiguous / two fronts), an unscaled
+// integer-operand divide — next to the library's own kernel on the same buffers and to pure
+// read / write / copy reference kernels.  Variants run in randomized order over interleaved rounds
+// (guide §5.4 rule 24); medians, minima and maxima are printed.  The logs of the five sweeps are
+// profiles/r01/tune_binop_v1..v5.log; edit the EXPX(...) list below to re-run a sweep.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ierased-cells_amd/csrc tools/tune_binop.hip -o tools/tune_binop
+//   ./tools/tune_binop [side=16384] [rounds=11] [iters=10]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -26,6 +33,21 @@
 using namespace ecd;
 using D2 = vec<double, 2>;
 
+// experimental: divide for operands that cannot over/underflow (integers): no v_div_scale / v_div_fmas
+__device__ __forceinline__ double int_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = a * r;
+    double rem = __builtin_fma(-b, q, a);
+    q = __builtin_fma(rem, r, q);
+    q = __builtin_amdgcn_div_fixup(q, b, a);
+    return (q != q) ? bits_f64(kNegQNaN) : q;
+}
+
+
 // store policies: 0 plain, 1 nt (builtin), 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 sc0, 6 nt sc0 sc1
 template <int POL>
 __device__ __forceinline__ void store16(D2* p, D2 v) {
@@ -38,14 +60,24 @@ __device__ __forceinline__ void store16(D2* p, D2 v) {
     else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
-template <int U, int BLOCK, bool WAVE_CONTIG, int STPOL, bool NTL, int OP>
+template <int U, int BLOCK, bool WAVE_CONTIG, int STPOL, bool NTL, int OP, int LDSKB = 0, int SLEEP = 0, int PERM = 0>
 __global__ __launch_bounds__(BLOCK) void k_exp(const uint8_t* __restrict__ l, const uint16_t* __restrict__ r,
                                                double* __restrict__ out, size_t n) {
     using L2 = vec<uint8_t, 2>;
     using R2 = vec<uint16_t, 2>;
+    if constexpr (LDSKB > 0) {  // occupancy cap: reserve LDS so fewer workgroups fit per CU
+        __shared__ volatile uint32_t pad[LDSKB * 256];
+        if (threadIdx.x == 0) pad[0] = 1;
+    }
     const size_t npairs = n >> 1;
     constexpr size_t TILE = size_t(BLOCK) * U;
-    const size_t tile = blockIdx.x;  // one block per tile; host guarantees npairs % TILE == 0
+    size_t tile = blockIdx.x;  // one block per tile; host guarantees npairs % TILE == 0
+    if constexpr (PERM == 1) {  // XCD-contiguous: blocks b, b+8, ... (same XCD) walk one contiguous eighth of the raster
+        const size_t per = gridDim.x / 8;
+        tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    } else if constexpr (PERM == 2) {  // two fronts: even blocks from the start, odd blocks from the end
+        tile = (blockIdx.x & 1) ? gridDim.x - 1 - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+    }
     size_t base, stride;
     if constexpr (WAVE_CONTIG) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -69,9 +101,15 @@ __global__ __launch_bounds__(BLOCK) void k_exp(const uint8_t* __restrict__ l, co
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         D2 o;
-        o.x = cell_op<OP, false>(to_f64(a[j].x), to_f64(b[j].x));
-        o.y = cell_op<OP, false>(to_f64(a[j].y), to_f64(b[j].y));
+        if constexpr (OP == 7) {
+            o.x = int_div(to_f64(a[j].x), to_f64(b[j].x));
+            o.y = int_div(to_f64(a[j].y), to_f64(b[j].y));
+        } else {
+            o.x = cell_op<OP, false>(to_f64(a[j].x), to_f64(b[j].x));
+            o.y = cell_op<OP, false>(to_f64(a[j].y), to_f64(b[j].y));
+        }
         store16<STPOL>(op + base + j * stride, o);
+        if constexpr (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
     }
 }
 
@@ -159,48 +197,32 @@ int main(int argc, char** argv) {
     add("ref write_tile U8 nt (8B/cell)", 8.0 * n, [=]() { k_write_tile<8, true><<<unsigned(n / 2 / (256 * 8)), 256>>>((u32x4*)out); });
     add("ref read_tile U8 (8B/cell)", 8.0 * n, [=]() { k_read_tile<8><<<unsigned(n / 2 / (256 * 8)), 256>>>((const u32x4*)out, sink); });
 
-    // baseline = library default (U8 blk256 interleaved, nt store, plain load)
-    EXP(8, 256, false, 1, false, EC_DIV, "div");
-    // store policy sweep
-    EXP(8, 256, false, 0, false, EC_DIV, "div");
-    EXP(8, 256, false, 2, false, EC_DIV, "div");
-    EXP(8, 256, false, 3, false, EC_DIV, "div");
-    EXP(8, 256, false, 4, false, EC_DIV, "div");
-    EXP(8, 256, false, 5, false, EC_DIV, "div");
-    EXP(8, 256, false, 6, false, EC_DIV, "div");
-    // nt loads
-    EXP(8, 256, false, 1, true, EC_DIV, "div");
-    EXP(8, 256, false, 0, true, EC_DIV, "div");
-    EXP(8, 256, false, 3, true, EC_DIV, "div");
-    // tile depth
-    EXP(2, 256, false, 1, false, EC_DIV, "div");
-    EXP(4, 256, false, 1, false, EC_DIV, "div");
-    EXP(16, 256, false, 1, false, EC_DIV, "div");
-    EXP(4, 256, false, 1, true, EC_DIV, "div");
-    EXP(16, 256, false, 1, true, EC_DIV, "div");
-    // workgroup size
-    EXP(8, 64, false, 1, false, EC_DIV, "div");
-    EXP(8, 128, false, 1, false, EC_DIV, "div");
-    EXP(8, 512, false, 1, false, EC_DIV, "div");
-    EXP(8, 1024, false, 1, false, EC_DIV, "div");
-    EXP(4, 512, false, 1, false, EC_DIV, "div");
-    EXP(4, 1024, false, 1, false, EC_DIV, "div");
-    EXP(4, 1024, false, 1, true, EC_DIV, "div");
-    // wave-contiguous tiles
-    EXP(8, 256, true, 1, false, EC_DIV, "div");
-    EXP(4, 256, true, 1, false, EC_DIV, "div");
-    EXP(8, 256, true, 1, true, EC_DIV, "div");
-    EXP(8, 512, true, 1, false, EC_DIV, "div");
-    // ALU-light op at the best-guess shapes (is the divide visible at all?)
-    EXP(8, 256, false, 1, false, EC_ADD, "add");
-    EXP(8, 256, false, 1, true, EC_ADD, "add");
-
+#define EXPX(U, BLOCK, STPOL, NTL, OPV, OPN, LDSKB, SLEEP, PERM)                                             \
+    if ((n / 2) % (size_t(BLOCK) * U) == 0 && ((n / 2) / (size_t(BLOCK) * U)) % 8 == 0)                      \
+        add(std::string("exp ") + OPN + " U" #U " blk" #BLOCK " ntl" #NTL " lds" #LDSKB "KB sleep" #SLEEP " perm" #PERM, b11, [=]() { \
+            k_exp<U, BLOCK, false, STPOL, NTL, OPV, LDSKB, SLEEP, PERM><<<unsigned((n / 2) / (size_t(BLOCK) * U)), BLOCK>>>(a, b, out, n); \
+        })
+    EXPX(2, 256, 1, true, EC_DIV, "div", 0, 0, 2);
+    EXPX(2, 256, 1, true, 7, "intdiv", 0, 0, 2);
+    EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 2);
+    EXPX(2, 512, 1, true, EC_DIV, "div", 0, 0, 2);
+    EXPX(2, 512, 1, true, 7, "intdiv", 0, 0, 2);
+    EXPX(4, 256, 1, true, 7, "intdiv", 0, 0, 2);
+    add("LIB k_binop_direct div U2 nt/nt (library kernel, same buffers)", b11, [=]() {
+        k_binop_direct<uint8_t, uint16_t, EC_DIV, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a, b, out, n); });
+    add("LIB k_binop_direct add U2 nt/nt (library kernel, same buffers)", b11, [=]() {
+        k_binop_direct<uint8_t, uint16_t, EC_ADD, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a, b, out, n); });
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     std::vector<unsigned long long> sums(vs.size(), 0);
+    unsigned long long rng = 12345;
     for (int round = -1; round < rounds; ++round) {
-        for (size_t vi = 0; vi < vs.size(); ++vi) {
+        std::vector<size_t> order(vs.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        if (round >= 0) { for (size_t i = order.size(); i > 1; --i) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; std::swap(order[i - 1], order[(rng >> 33) % i]); } }
+        for (size_t oi = 0; oi < order.size(); ++oi) {
+            size_t vi = order[oi];
             Variant& v = vs[vi];
             if (round < 0) {
                 CK(hipMemset(out, 0xEE, 64));
@@ -220,13 +242,13 @@ int main(int argc, char** argv) {
             v.ms.push_back(ms / iters);
         }
     }
-    printf("%-52s %9s %9s %9s %8s  %s\n", "variant", "med_ms", "min_ms", "GB/s", "%of8TB", "checksum");
+    printf("%-52s %9s %9s %9s %9s %8s  %s\n", "variant", "med_ms", "min_ms", "max_ms", "GB/s", "%of8TB", "checksum");
     for (size_t vi = 0; vi < vs.size(); ++vi) {
         Variant& v = vs[vi];
         std::sort(v.ms.begin(), v.ms.end());
         float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
         double gbs = v.bytes / (med * 1e-3) / 1e9;
-        printf("%-52s %9.4f %9.4f %9.1f %7.1f%%  %016llx\n", v.name.c_str(), med, mn, gbs, gbs / 80.0, sums[vi]);
+        printf("%-52s %9.4f %9.4f %9.4f %9.1f %7.1f%%  %016llx\n", v.name.c_str(), med, mn, v.ms.back(), gbs, gbs / 80.0, sums[vi]);
     }
     return 0;
 }
