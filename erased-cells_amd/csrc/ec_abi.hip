@@ -318,7 +318,7 @@ extern "C" ec_status ec_init(int32_t device) {
     g_device = device;
     g_inited = true;
     t_bound_device = device;
-    return EC_OK;
+    return EC_OK;  // (reduction scratch for the default stream is created by ec_prepare_stream / first use)
 }
 
 extern "C" ec_status ec_shutdown(void) {
@@ -389,8 +389,16 @@ extern "C" ec_status ec_stream_create(ec_stream* out) {
     if (st != EC_OK) return st;
     hipStream_t s;
     st = check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
-    if (st == EC_OK) *out = s;
-    return st;
+    if (st != EC_OK) return st;
+    *out = s;
+    return ec_prepare_stream(s);
+}
+
+extern "C" ec_status ec_prepare_stream(ec_stream stream) {
+    ec_status st = ensure_init();
+    if (st != EC_OK) return st;
+    Scratch sc;
+    return get_scratch(S(stream), &sc);  // allocates this stream's reduction scratch now, not at first use
 }
 extern "C" ec_status ec_stream_destroy(ec_stream s) {
     {

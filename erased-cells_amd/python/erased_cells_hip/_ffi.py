@@ -57,6 +57,7 @@ SIGNATURES = {
     "ec_download": (I32, [VP, VP, SZ, VP]),
     "ec_copy": (I32, [VP, VP, SZ, VP]),
     "ec_stream_create": (I32, [C.POINTER(VP)]),
+    "ec_prepare_stream": (I32, [VP]),
     "ec_stream_destroy": (I32, [VP]),
     "ec_stream_sync": (I32, [VP]),
     "ec_binop": (I32, [I32, C.c_uint8, VP, C.c_uint8, VP, SZ, VP, VP]),
@@ -102,6 +103,14 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and loads it by a different
+        # file name than this library's DT_NEEDED entry.  If torch comes second it brings up a second
+        # runtime copy that cannot see the device; if torch is loaded first the dynamic loader resolves
+        # our libamdhip64.so.7 to torch's copy and both share one runtime.  So: torch first, when present.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(SO_PATH):
             raise ImportError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"(or `make -C {CSRC}`); there is no CPU fallback")

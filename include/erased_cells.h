@@ -111,6 +111,11 @@ ec_status ec_upload(void *dst_dev, const void *src_host, size_t bytes, ec_stream
 ec_status ec_download(void *dst_host, const void *src_dev, size_t bytes, ec_stream stream); /* to_vec; waits for completion */
 ec_status ec_copy(void *dst_dev, const void *src_dev, size_t bytes, ec_stream stream);      /* Clone (buffer.rs:151-153) */
 ec_status ec_stream_create(ec_stream *out);
+/* Allocates the per-stream reduction scratch of a stream the library did not create (NULL = default
+ * stream, a torch stream, ...).  After this, every asynchronous entry point — including ec_min_max_keys and
+ * ec_mask_counts_device — performs no allocation and no synchronisation, so a chain of calls can be
+ * captured into a hipGraph on that stream and replayed. */
+ec_status ec_prepare_stream(ec_stream stream);
 ec_status ec_stream_destroy(ec_stream s);
 ec_status ec_stream_sync(ec_stream s);
 

@@ -156,3 +156,33 @@ def test_config4_min_max_u16_65536sq_planted_and_sharded(ec):
     assert tot == t
     nt, nf = (~mask).counts()
     assert (nt, nf) == (f, t)
+
+
+def test_indexing_beyond_2_32_cells(ec):
+    """More than 2^32 cells in one buffer (a 65537 x 65537 u8 raster, odd length): 64-bit indexing in the
+    element-wise, map and reduction kernels; spot-checked on slices against the oracle."""
+    L = ec.lib()
+    n = 65537 * 65537  # 4,295,098,369 cells
+    a, b = ec.CellBuffer.empty(n, ec.UInt8), ec.CellBuffer.empty(n, ec.UInt8)
+    _chk(ec, L.ec_synth_fill(ec.UInt8, a.mem.ptr, n, 0x5EED0021, 0, 0.0, 255.0, None))
+    _chk(ec, L.ec_synth_fill(ec.UInt8, b.mem.ptr, n, 0x5EED0022, 0, 1.0, 255.0, None))
+    out = a / b                      # 34 GB of f64
+    wide = a.convert(ec.UInt16)      # k_map
+    neg = -a                         # u8 -> i16
+    spots = [0, (1 << 32) - 70000, (1 << 32) - 5, n - 100003]
+    for off in spots:
+        ln = min(100003, n - off)
+        ha = eco.fill_u8(ln, 0x5EED0021, base=off)
+        hb = eco.fill_u8(ln, 0x5EED0022, base=off, lo=1)
+        assert np.array_equal(a.shard(off, ln).to_numpy(), ha)
+        _assert_same_bits(out.shard(off, ln).to_numpy(), eco.f_binop(eco.DIV, ha, hb))
+        assert np.array_equal(wide.shard(off, ln).to_numpy(), ha.astype(np.uint16))
+        assert np.array_equal(neg.shard(off, ln).to_numpy(), -ha.astype(np.int16))
+    mn, mx = out.min_max()
+    assert (mn.value, mx.value) == (0.0, 255.0)
+    a.put(n - 1, ec.CellValue(ec.UInt8, 0))
+    b.put(n - 1, ec.CellValue(ec.UInt8, 1))
+    m = ec.mask_from_nodata(a, ec.NoData.default())     # zeros are nodata
+    t, f = m.counts()
+    assert t + f == n and abs(f / n - 1 / 256) < 1e-4
+    assert ec.MaskedCellBuffer(a, m).min_max()[0].value == 1

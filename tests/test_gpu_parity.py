@@ -355,6 +355,76 @@ def test_fused_masked_expression_equals_eager_chain(ec):
         assert got.counts() == exp.counts()
 
 
+def test_streams_threads_and_graph_capture(ec):
+    """Re-entrancy: concurrent host threads on distinct streams (per-stream reduction scratch, per-thread
+    device binding), and a chain of asynchronous calls captured into a hipGraph and replayed."""
+    import ctypes as C
+    import threading
+    L = ec.lib()
+    n = 1 << 20
+    inputs = [(rand_cells(eco.U16, n, 600 + i), rand_cells(eco.U16, n, 700 + i)) for i in range(4)]
+    results = [None] * 4
+
+    def worker(i):
+        s = C.c_void_p()
+        ec._ffi.check(L.ec_stream_create(C.byref(s)))
+        try:
+            a, b = inputs[i]
+            da, db = ec.DeviceMem(a.nbytes), ec.DeviceMem(b.nbytes)
+            out, keys = ec.DeviceMem(n * 8), ec.DeviceMem(16)
+            ec._ffi.check(L.ec_upload(da.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes, s))
+            ec._ffi.check(L.ec_upload(db.ptr, b.ctypes.data_as(C.c_void_p), b.nbytes, s))
+            k = np.empty(2, np.int64)
+            for _ in range(20):
+                ec._ffi.check(L.ec_binop(ec.DIV, ec.UInt16, da.ptr, ec.UInt16, db.ptr, n, out.ptr, s))
+                ec._ffi.check(L.ec_min_max_keys(ec.Float64, out.ptr, None, n, keys.ptr, s))
+            ec._ffi.check(L.ec_download(k.ctypes.data_as(C.c_void_p), keys.ptr, 16, s))
+            results[i] = (int(k[0]), int(k[1]))
+        finally:
+            ec._ffi.check(L.ec_stream_destroy(s))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    from erased_cells_hip import sharded
+    for i, (a, b) in enumerate(inputs):
+        mn, mx = sharded.combine_min_max_keys(ec.Float64, results[i])
+        emn, emx = eco.f_min_max(eco.f_binop(eco.DIV, a, b))
+        assert (mn.bits(), mx.bits()) == (emn.bits(), emx.bits()), i
+
+    # hipGraph: capture NDVI (fused) + min_max keys on a torch stream, replay after changing the inputs
+    import torch
+    side = torch.cuda.Stream()
+    ec._ffi.check(L.ec_prepare_stream(side.cuda_stream))
+    nir, red = rand_cells(eco.U16, n, 801), rand_cells(eco.U16, n, 802)
+    t_nir, t_red = torch.from_numpy(nir.view(np.int16)).cuda(), torch.from_numpy(red.view(np.int16)).cuda()
+    t_out = torch.empty(n, dtype=torch.float64, device="cuda")
+    t_keys = torch.zeros(2, dtype=torch.int64, device="cuda")
+    dt4 = (C.c_uint8 * 4)(ec.UInt16, ec.UInt16, ec.UInt16, ec.UInt16)
+    p4 = (C.c_void_p * 4)(t_nir.data_ptr(), t_red.data_ptr(), t_nir.data_ptr(), t_red.data_ptr())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        h = torch.cuda.current_stream().cuda_stream
+        ec._ffi.check(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, n, t_out.data_ptr(), h))
+        ec._ffi.check(L.ec_min_max_keys(ec.Float64, t_out.data_ptr(), None, n, t_keys.data_ptr(), h))
+    for trial in range(2):
+        if trial == 1:  # new inputs in the same buffers, same graph
+            nir, red = rand_cells(eco.U16, n, 803), rand_cells(eco.U16, n, 804)
+            t_nir.copy_(torch.from_numpy(nir.view(np.int16)))
+            t_red.copy_(torch.from_numpy(red.view(np.int16)))
+        g.replay()
+        torch.cuda.synchronize()
+        exp = eco.f_binop(eco.DIV, eco.f_binop(eco.SUB, nir, red), eco.f_binop(eco.ADD, nir, red))
+        assert np.array_equal(bits_of(t_out.cpu().numpy()), bits_of(exp))
+        k = t_keys.cpu().numpy()
+        mn, mx = sharded.combine_min_max_keys(ec.Float64, (int(k[0]), int(k[1])))
+        emn, emx = eco.f_min_max(exp)
+        assert (mn.bits(), mx.bits()) == (emn.bits(), emx.bits())
+
+
 @pytest.mark.timeout(300)
 def test_native_rccl_allreduce_of_reduction_payloads(ec):
     """ec_allreduce_min_max_keys / ec_allreduce_counts drive RCCL directly (no torch): a 1-rank
