@@ -55,6 +55,8 @@ def parse():
                     help="torch.distributed backend; nccl (= RCCL over xGMI) is the product path, gloo only for rehearsals")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses device 0 (implies nothing about scaling)")
+    ap.add_argument("--ramp", type=int, default=60,
+                    help="minimum untimed launches before timing (clock ramp); extra ones beyond --warmup are reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true",
                     help="also time from_vec (H2D) + divide + to_vec (D2H) once; reported beside, never as `value`")
@@ -229,8 +231,12 @@ def main():
         bytes_per_cell, kernel = 24, "k_fused (a+b)*c f32 + 3 masks, one pass"
         wl = wl.replace("eager", "fused")
 
-    # ---- warm-up, then EXACTLY `steps` timed steps between barrier+synchronize
-    for _ in range(args.warmup):
+    # ---- clock ramp + warm-up, then EXACTLY `steps` timed steps between barrier+synchronize.
+    # The first ≈50 launches after idle run ≈5 % slow while the GPU's clocks ramp
+    # (profiles/r01/warmup_sensitivity.txt); if the caller asks for fewer warm-up steps than that, the
+    # difference is run first as untimed, disclosed ramp steps (config.clock_ramp_steps).
+    ramp = max(0, args.ramp - args.warmup)
+    for _ in range(ramp + args.warmup):
         step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -266,7 +272,8 @@ def main():
             "config": {"workload": wl, "rows": rows_total, "cols": side, "cells": total_cells,
                        "cells_per_gpu": n, "sharding": "contiguous row-block per rank, no data-path collective",
                        "inputs": "splitmix64 counter streams generated on device, resident in HBM",
-                       "kernel_variant": "lds" if (args.variant or 0) == 1 else "direct"},
+                       "kernel_variant": "lds" if (args.variant or 0) == 1 else "direct",
+                       "clock_ramp_steps": ramp},
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": recorded_traffic(n) if (args.workload == "div_u8_u16" and world == 1) else None,

@@ -77,6 +77,15 @@ __global__ __launch_bounds__(BLOCK) void k_exp(const uint8_t* __restrict__ l, co
         tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
     } else if constexpr (PERM == 2) {  // two fronts: even blocks from the start, odd blocks from the end
         tile = (blockIdx.x & 1) ? gridDim.x - 1 - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+    } else if constexpr (PERM == 3) {  // two fronts, decoupled from XCD parity: groups of 8 consecutive blocks alternate
+        const size_t g = blockIdx.x >> 3, r = blockIdx.x & 7, k = (g >> 1) * 8 + r;
+        tile = (g & 1) ? gridDim.x - 1 - k : k;
+    } else if constexpr (PERM == 4) {  // four fronts (b & 3): quarters walked forward
+        const size_t per = gridDim.x / 4;
+        tile = (blockIdx.x & 3) * per + (blockIdx.x >> 2);
+    } else if constexpr (PERM == 5) {  // four fronts: two from the start of each half, two from the ends
+        const size_t half = gridDim.x / 2, f = blockIdx.x & 3, k = blockIdx.x >> 2;
+        tile = f == 0 ? k : f == 1 ? half - 1 - k : f == 2 ? half + k : gridDim.x - 1 - k;
     }
     size_t base, stride;
     if constexpr (WAVE_CONTIG) {
@@ -202,12 +211,16 @@ int main(int argc, char** argv) {
         add(std::string("exp ") + OPN + " U" #U " blk" #BLOCK " ntl" #NTL " lds" #LDSKB "KB sleep" #SLEEP " perm" #PERM, b11, [=]() { \
             k_exp<U, BLOCK, false, STPOL, NTL, OPV, LDSKB, SLEEP, PERM><<<unsigned((n / 2) / (size_t(BLOCK) * U)), BLOCK>>>(a, b, out, n); \
         })
+    EXPX(2, 256, 1, true, EC_DIV, "div", 0, 0, 0);
     EXPX(2, 256, 1, true, EC_DIV, "div", 0, 0, 2);
-    EXPX(2, 256, 1, true, 7, "intdiv", 0, 0, 2);
+    EXPX(2, 256, 1, true, EC_DIV, "div", 0, 0, 3);
+    EXPX(2, 256, 1, true, EC_DIV, "div", 0, 0, 4);
+    EXPX(2, 256, 1, true, EC_DIV, "div", 0, 0, 5);
+    EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 0);
     EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 2);
-    EXPX(2, 512, 1, true, EC_DIV, "div", 0, 0, 2);
-    EXPX(2, 512, 1, true, 7, "intdiv", 0, 0, 2);
-    EXPX(4, 256, 1, true, 7, "intdiv", 0, 0, 2);
+    EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 3);
+    EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 4);
+    EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 5);
     add("LIB k_binop_direct div U2 nt/nt (library kernel, same buffers)", b11, [=]() {
         k_binop_direct<uint8_t, uint16_t, EC_DIV, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a, b, out, n); });
     add("LIB k_binop_direct add U2 nt/nt (library kernel, same buffers)", b11, [=]() {
