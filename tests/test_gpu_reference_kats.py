@@ -354,3 +354,26 @@ def test_read_cells_masked_ndvi_sharded(ec, golden_dir):
     assert (data, nodata) == (31430, 4)
     smn, smx = sharded.combine_min_max_keys(ec.Float64, (key_lo, key_hi))
     assert float(smn.value).hex() == NDVI_MIN_HEX and float(smx.value).hex() == NDVI_MAX_HEX
+
+
+@pytest.mark.parametrize("world,fused", [(1, False), (2, False), (4, True)])
+def test_config5_example_multi_process(world, fused):
+    """examples/ndvi_sharded.py: one process per rank (gloo rehearsal of the RCCL exchange on one GPU)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = os.path.join(root, "examples", "ndvi_sharded.py")
+    extra = ["--backend", "gloo", "--single-device"] + (["--fused"] if fused else [])
+    if world == 1:
+        cmd = [sys.executable, script] + extra
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), script] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "matches the reference's known answers" in r.stdout
