@@ -9,11 +9,11 @@
 // fully coalesced).  The narrow operand streams are moved in one of two ways:
 //   DIRECT  lane-contiguous narrow loads: 2 cells per lane per chunk
 //           (ushort / dword / dwordx2 / dwordx4 by operand width).
-//   LDS     the wave loads its whole tile of a ≤2-byte operand with 16-B-per-lane
-//           coalesced loads into a wave-private LDS slab, then each lane reads
-//           back the two cells that belong to its 16-B output slot and widens
-//           them ("LDS staging for the widening step").  The slab is private
-//           to the wave, so no workgroup barrier is needed.
+//   LDS     the wave loads its whole 256-cell tile of a ≤4-byte operand with ONE
+//           load of 4*sizeof(T) bytes per lane into a wave-private LDS slab, then
+//           each lane reads back the two cells that belong to each 16-B output
+//           slot and widens them ("LDS staging for the widening step").  The slab
+//           is private to the wave, so no workgroup barrier is needed.
 // One workgroup per tile of U chunks per wave, straight-line code, grid = number
 // of tiles (≫ 256 CUs: 65,536 workgroups at 16384²).  Loads and stores are
 // non-temporal: every byte is touched once and the streams (2.95 GB) dwarf the
@@ -172,75 +172,62 @@ __global__ __launch_bounds__(kBlock) void k_binop_scalar_cellwise(const L* __res
 }
 
 // ---------------------------------------------------------------------------
-// LDS-staged variant.  Wave tile = 128*U cells (U chunks of one dwordx4 store
-// per lane).  Operands of ≤2 bytes are staged through a wave-private LDS slab
-// with 16-B-per-lane loads; wider operands already load ≥8 B per lane and go
-// direct.  U*sizeof(T) must be a multiple of 8 so the slab is whole 1-KiB rows.
+// LDS-staged variant ("LDS staging for the widening step").  Wave tile = 256 cells = two chunks of
+// one dwordx4 store per lane (the tile depth that is fastest for DIRECT too).  An operand of ≤4
+// bytes is fetched with ONE load of 4*sizeof(T) bytes per lane (dword / dwordx2 / dwordx4: half the
+// global load instructions of DIRECT), written to a wave-private LDS slab, and each lane reads back
+// the two cells that belong to each of its two 16-B output slots, widens them and stores.  The slab
+// is private to the wave, so a wavefront-scope fence orders write -> read; no workgroup barrier.
+// 8-byte operands already load 16 B per lane and go direct.
 // ---------------------------------------------------------------------------
-template <typename T, int U>
+constexpr int kLdsChunks = 2;                        // chunks per wave tile
+constexpr size_t kLdsWaveCells = 128 * kLdsChunks;   // 256 cells
+
+template <typename T>
 struct Staged {
-    static constexpr bool value = sizeof(T) <= 2;
-    static constexpr int kBytes = 128 * U * int(sizeof(T));  // per wave tile
-    static constexpr int kRows = kBytes / 1024;              // 16-B loads per lane
-    static_assert(!value || (kBytes % 1024 == 0), "U*sizeof(T) must be a multiple of 8");
+    static constexpr bool value = sizeof(T) <= 4;
+    using Load = vec<uint32_t, int(sizeof(T))>;                        // 4*sizeof(T) bytes per lane
+    static constexpr int kSlabBytes = value ? int(kLdsWaveCells * sizeof(T)) : 16;
 };
 
 using u32x4 = vec<uint32_t, 4>;
 
-template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
+template <typename L, typename R, int OP, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_lds_body(const L* __restrict__ l, const R* __restrict__ r,
                                                double* __restrict__ out, size_t n) {
     using L2 = vec<L, 2>;
     using R2 = vec<R, 2>;
     using D2 = vec<double, 2>;
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
-    constexpr bool SL = Staged<L, U>::value, SR = Staged<R, U>::value;
-    constexpr int LB = SL ? Staged<L, U>::kBytes : 16, RB = SR ? Staged<R, U>::kBytes : 16;
-    constexpr size_t WTILE = 128 * size_t(U);  // cells per wave tile
+    constexpr bool SL = Staged<L>::value, SR = Staged<R>::value;
 
-    __shared__ __attribute__((aligned(16))) unsigned char slab_l[kWavesPerBlock][LB];
-    __shared__ __attribute__((aligned(16))) unsigned char slab_r[kWavesPerBlock][RB];
+    __shared__ __attribute__((aligned(16))) unsigned char slab_l[kWavesPerBlock][Staged<L>::kSlabBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char slab_r[kWavesPerBlock][Staged<R>::kSlabBytes];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    const size_t nfull = n / WTILE;  // whole wave tiles
-    const size_t gwaves = size_t(gridDim.x) * kWavesPerBlock;
-
-    // tiles are dealt block-major so a block's four waves stream 4 adjacent tiles
-    for (size_t t = size_t(blockIdx.x) * kWavesPerBlock + wave; t < nfull; t += gwaves) {
-        const size_t cell0 = t * WTILE;
-        u32x4 sl[SL ? Staged<L, U>::kRows : 1];
-        u32x4 sr[SR ? Staged<R, U>::kRows : 1];
-        L2 a[U];
-        R2 b[U];
+    const size_t nfull = n / kLdsWaveCells;  // whole wave tiles
+    const size_t t = two_front_tile() * kWavesPerBlock + wave;
+    if (t < nfull) {
+        const size_t cell0 = t * kLdsWaveCells;
+        L2 a[kLdsChunks];
+        R2 b[kLdsChunks];
+        typename Staged<L>::Load sl{};
+        typename Staged<R>::Load sr{};
         if constexpr (SL) {
-            const u32x4* g = reinterpret_cast<const u32x4*>(l + cell0);
-#pragma unroll
-            for (int k = 0; k < Staged<L, U>::kRows; ++k) sl[k] = load_vec<NT_LD>(g + k * kWave + lane);
+            sl = load_vec<NT_LD>(reinterpret_cast<const typename Staged<L>::Load*>(l + cell0) + lane);
         } else {
-            const L2* g = reinterpret_cast<const L2*>(l + cell0);
 #pragma unroll
-            for (int j = 0; j < U; ++j) a[j] = load_vec<NT_LD>(g + j * kWave + lane);
+            for (int j = 0; j < kLdsChunks; ++j) a[j] = load_vec<NT_LD>(reinterpret_cast<const L2*>(l + cell0) + j * kWave + lane);
         }
         if constexpr (SR) {
-            const u32x4* g = reinterpret_cast<const u32x4*>(r + cell0);
-#pragma unroll
-            for (int k = 0; k < Staged<R, U>::kRows; ++k) sr[k] = load_vec<NT_LD>(g + k * kWave + lane);
+            sr = load_vec<NT_LD>(reinterpret_cast<const typename Staged<R>::Load*>(r + cell0) + lane);
         } else {
-            const R2* g = reinterpret_cast<const R2*>(r + cell0);
 #pragma unroll
-            for (int j = 0; j < U; ++j) b[j] = load_vec<NT_LD>(g + j * kWave + lane);
+            for (int j = 0; j < kLdsChunks; ++j) b[j] = load_vec<NT_LD>(reinterpret_cast<const R2*>(r + cell0) + j * kWave + lane);
         }
-        if constexpr (SL) {
-            u32x4* s = reinterpret_cast<u32x4*>(slab_l[wave]);
-#pragma unroll
-            for (int k = 0; k < Staged<L, U>::kRows; ++k) s[k * kWave + lane] = sl[k];
-        }
-        if constexpr (SR) {
-            u32x4* s = reinterpret_cast<u32x4*>(slab_r[wave]);
-#pragma unroll
-            for (int k = 0; k < Staged<R, U>::kRows; ++k) s[k * kWave + lane] = sr[k];
-        }
+        if constexpr (SL) reinterpret_cast<typename Staged<L>::Load*>(slab_l[wave])[lane] = sl;
+        if constexpr (SR) reinterpret_cast<typename Staged<R>::Load*>(slab_r[wave])[lane] = sr;
         if constexpr (SL || SR) {
             // the slab is private to this wave: order the wave's own LDS writes before its reads
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -248,34 +235,26 @@ __device__ __forceinline__ void binop_lds_body(const L* __restrict__ l, const R*
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if constexpr (SL) {
-            const L2* s = reinterpret_cast<const L2*>(slab_l[wave]);
 #pragma unroll
-            for (int j = 0; j < U; ++j) a[j] = s[j * kWave + lane];
+            for (int j = 0; j < kLdsChunks; ++j) a[j] = reinterpret_cast<const L2*>(slab_l[wave])[j * kWave + lane];
         }
         if constexpr (SR) {
-            const R2* s = reinterpret_cast<const R2*>(slab_r[wave]);
 #pragma unroll
-            for (int j = 0; j < U; ++j) b[j] = s[j * kWave + lane];
+            for (int j = 0; j < kLdsChunks; ++j) b[j] = reinterpret_cast<const R2*>(slab_r[wave])[j * kWave + lane];
         }
         D2* o2 = reinterpret_cast<D2*>(out + cell0);
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
+        for (int j = 0; j < kLdsChunks; ++j) {
             D2 o;
             o.x = cell_op<OP, FP>(to_f64(a[j].x), to_f64(b[j].x));
             o.y = cell_op<OP, FP>(to_f64(a[j].y), to_f64(b[j].y));
             store_vec<NT_ST>(o2 + j * kWave + lane, o);
         }
-        if constexpr (SL || SR) {
-            // next iteration overwrites the slab: keep this iteration's reads ahead of those writes
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
     }
-    // ragged tail (< one wave tile): cell-wise by the whole grid
-    const size_t tail0 = nfull * WTILE;
-    const size_t stride = size_t(gridDim.x) * kBlock;
-    for (size_t i = tail0 + size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
-        out[i] = cell_op<OP, FP>(to_f64(l[i]), to_f64(r[i]));
+    // ragged tail (< one wave tile): cell-wise by workgroup 0
+    if (blockIdx.x == 0)
+        for (size_t i = nfull * kLdsWaveCells + threadIdx.x; i < n; i += kBlock)
+            out[i] = cell_op<OP, FP>(to_f64(l[i]), to_f64(r[i]));
 }
 
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
@@ -284,10 +263,10 @@ __global__ __launch_bounds__(kBlock) void k_binop_direct(const L* __restrict__ l
     binop_direct_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
 }
 
-template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
+template <typename L, typename R, int OP, bool NT_ST, bool NT_LD>
 __global__ __launch_bounds__(kBlock) void k_binop_lds(const L* __restrict__ l, const R* __restrict__ r,
                                                       double* __restrict__ out, size_t n) {
-    binop_lds_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
+    binop_lds_body<L, R, OP, NT_ST, NT_LD>(l, r, out, n);
 }
 
 // `&Mask & &Mask` (src/masked/mask.rs:129-140) as a block-tiled 16-B-per-lane stream.
@@ -312,7 +291,7 @@ template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD, bool LD
 __global__ __launch_bounds__(kBlock) void k_masked_binop(const L* __restrict__ l, const uint8_t* __restrict__ lm,
                                                          const R* __restrict__ r, const uint8_t* __restrict__ rm,
                                                          double* __restrict__ out, uint8_t* __restrict__ om, size_t n) {
-    if constexpr (LDS) binop_lds_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
+    if constexpr (LDS) binop_lds_body<L, R, OP, NT_ST, NT_LD>(l, r, out, n);
     else binop_direct_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
     mask_and_body(lm, rm, om, n);
 }

@@ -21,10 +21,10 @@ static ec_status launch_binop_pair(const void* l, const void* r, size_t n, doubl
         k_binop_cellwise<L, R, OP><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, rp, out, n);
         return check_launch("binop(cellwise)");
     }
-    constexpr bool kCanStage = Staged<L, kLdsU>::value || Staged<R, kLdsU>::value;
+    constexpr bool kCanStage = Staged<L>::value || Staged<R>::value;
     if (kCanStage && tu.binop_variant == 1) {
-        const size_t tiles = (n / (128 * size_t(kLdsU)) + kWavesPerBlock - 1) / kWavesPerBlock;
-        k_binop_lds<L, R, OP, kLdsU, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n);
+        const size_t tiles = (n / kLdsWaveCells + kWavesPerBlock - 1) / kWavesPerBlock;
+        k_binop_lds<L, R, OP, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n);
         return check_launch("binop(lds)");
     }
     const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
@@ -43,10 +43,10 @@ static ec_status launch_masked_pair(const void* l, const uint8_t* lm, const void
         k_masked_binop_cellwise<L, R, OP><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
         return check_launch("masked_binop(cellwise)");
     }
-    constexpr bool kCanStage = Staged<L, kLdsU>::value || Staged<R, kLdsU>::value;
+    constexpr bool kCanStage = Staged<L>::value || Staged<R>::value;
     if (kCanStage && tu.binop_variant == 1) {
-        const size_t tiles = (n / (128 * size_t(kLdsU)) + kWavesPerBlock - 1) / kWavesPerBlock;
-        k_masked_binop<L, R, OP, kLdsU, kNtStore, kNtLoad, true><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
+        const size_t tiles = (n / kLdsWaveCells + kWavesPerBlock - 1) / kWavesPerBlock;
+        k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, true><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
         return check_launch("masked_binop(lds)");
     }
     const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);

@@ -13,7 +13,6 @@ namespace ecd {
 // Compile-time launch shape of the binary-arithmetic kernels; chosen from the
 // A/B runs recorded in profiles/ (tools/tune_binop.hip).
 constexpr int kBinopU = 2;         // chunks of 128 cells per wave per tile (U = 2 beats 8 by ≈6 %: tune_binop_v4/v5.log)
-constexpr int kLdsU = 8;           // the LDS-staged variant needs whole 1-KiB slab rows (U * sizeof(T) % 8 == 0)
 constexpr bool kNtStore = true;    // streaming f64 output: 2.1 GB ≫ 256 MiB Infinity Cache
 constexpr bool kNtLoad = true;     // +6 % on the divide (tune_binop_v2.log: 6270 -> 6666 GB/s)
 constexpr int kReduceU = 4;

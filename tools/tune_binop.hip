@@ -122,6 +122,40 @@ __global__ __launch_bounds__(BLOCK) void k_exp(const uint8_t* __restrict__ l, co
     }
 }
 
+// LDS-staged counterpart of the best DIRECT shape (U = 2, 256 cells per wave): the wave loads its u8 tile
+// with one dword per lane and its u16 tile with one dwordx2 per lane (half the global load instructions of
+// DIRECT), stages both in a wave-private LDS slab and reads back the two cells of each output slot.
+template <int STPOL, bool NTL, int OP, int PERM>
+__global__ __launch_bounds__(256) void k_lds2(const uint8_t* __restrict__ l, const uint16_t* __restrict__ r,
+                                              double* __restrict__ out, size_t n) {
+    __shared__ __attribute__((aligned(16))) unsigned char slab_a[4][256];
+    __shared__ __attribute__((aligned(16))) unsigned char slab_b[4][512];
+    size_t blk = blockIdx.x;
+    if constexpr (PERM == 2) blk = (blockIdx.x & 1) ? gridDim.x - 1 - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t cell0 = (blk * 4 + wave) * 256;  // host guarantees n % 1024 == 0
+    if (cell0 + 256 > n) return;
+    const uint32_t av = load_vec<NTL>(reinterpret_cast<const uint32_t*>(l + cell0) + lane);
+    const vec<uint32_t, 2> bv = load_vec<NTL>(reinterpret_cast<const vec<uint32_t, 2>*>(r + cell0) + lane);
+    reinterpret_cast<uint32_t*>(slab_a[wave])[lane] = av;
+    reinterpret_cast<vec<uint32_t, 2>*>(slab_b[wave])[lane] = bv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    using L2 = vec<uint8_t, 2>;
+    using R2 = vec<uint16_t, 2>;
+    D2* op = reinterpret_cast<D2*>(out + cell0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const L2 a = reinterpret_cast<const L2*>(slab_a[wave])[j * 64 + lane];
+        const R2 b = reinterpret_cast<const R2*>(slab_b[wave])[j * 64 + lane];
+        D2 o;
+        o.x = cell_op<OP, false>(to_f64(a.x), to_f64(b.x));
+        o.y = cell_op<OP, false>(to_f64(a.y), to_f64(b.y));
+        store16<STPOL>(op + j * 64 + lane, o);
+    }
+}
+
 __global__ void k_fill(uint8_t* a, uint16_t* b, size_t n) {
     size_t stride = size_t(gridDim.x) * blockDim.x;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -221,6 +255,11 @@ int main(int argc, char** argv) {
     EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 3);
     EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 4);
     EXPX(2, 256, 1, true, EC_ADD, "add", 0, 0, 5);
+    if (n % 1024 == 0) {
+        add("lds2 div U2 wave-private slab, dword/dwordx2 loads, perm2", b11, [=]() { k_lds2<1, true, EC_DIV, 2><<<unsigned(n / 1024), 256>>>(a, b, out, n); });
+        add("lds2 div U2 wave-private slab, dword/dwordx2 loads, perm0", b11, [=]() { k_lds2<1, true, EC_DIV, 0><<<unsigned(n / 1024), 256>>>(a, b, out, n); });
+        add("lds2 add U2 wave-private slab, dword/dwordx2 loads, perm2", b11, [=]() { k_lds2<1, true, EC_ADD, 2><<<unsigned(n / 1024), 256>>>(a, b, out, n); });
+    }
     add("LIB k_binop_direct div U2 nt/nt (library kernel, same buffers)", b11, [=]() {
         k_binop_direct<uint8_t, uint16_t, EC_DIV, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a, b, out, n); });
     add("LIB k_binop_direct add U2 nt/nt (library kernel, same buffers)", b11, [=]() {
