@@ -132,8 +132,12 @@ def main():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     dev = 0 if args.single_device else local_rank
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("EC_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal of the RCCL path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
@@ -156,7 +160,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -223,7 +227,7 @@ def main():
 
         def step():
             chk(L.ec_min_max_keys(ec.UInt16, a.mem.ptr, None, n, keys.data_ptr(), stream))
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(keys, op=dist.ReduceOp.MAX)
 
     if args.workload == "masked_chain" and args.fused:
@@ -250,7 +254,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream
 
     tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, dev_ms = float(tt[0]), float(tt[1])
 
@@ -292,7 +296,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "div_u8_u16":
             res["cpu_baseline"] = cpu_baseline(side, args.cpu_seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
