@@ -116,6 +116,21 @@ def recorded_traffic(cells_per_launch: int):
     return None
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout when its communicator comes up; this program's stdout
+    carries exactly one JSON line, so fd 1 is pointed at fd 2 while the process group initialises."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     args = parse()
     import torch
@@ -138,10 +153,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group("gloo")
+        with _StdoutToStderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            else:
+                dist.init_process_group("gloo")
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)  # brings the communicator up (and its banner out) before anything is timed
+            torch.cuda.synchronize()
 
     import erased_cells_hip as ec
     from erased_cells_hip import sharded
