@@ -318,6 +318,14 @@ extern "C" ec_status ec_init(int32_t device) {
     g_device = device;
     g_inited = true;
     t_bound_device = device;
+    // Stream-ordered allocations (ec_alloc_async) come from the device's default memory pool; keep freed
+    // blocks cached in the pool instead of returning them to the OS at every synchronisation.
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
     return EC_OK;  // (reduction scratch for the default stream is created by ec_prepare_stream / first use)
 }
 
@@ -363,6 +371,21 @@ extern "C" ec_status ec_alloc(void** dptr, size_t bytes) {
     return check_hip(hipMalloc(dptr, bytes), "hipMalloc");
 }
 extern "C" ec_status ec_free(void* dptr) { return dptr ? check_hip(hipFree(dptr), "hipFree") : EC_OK; }
+
+// Result buffers of eager operators are allocated per call (the reference `collect()`s a fresh Vec);
+// hipMalloc/hipFree cost 0.2-0.4 ms per pair — as much as the 16384² kernel itself — and hipFree
+// synchronises.  The stream-ordered pool makes both a queue operation (tools/alloc_cost.py).
+extern "C" ec_status ec_alloc_async(void** dptr, size_t bytes, ec_stream stream) {
+    if (!dptr) return set_error(EC_ERR_ARG, "ec_alloc_async: null out pointer");
+    ec_status st = ensure_init();
+    if (st != EC_OK) return st;
+    *dptr = nullptr;
+    if (bytes == 0) return EC_OK;
+    return check_hip(hipMallocAsync(dptr, bytes, S(stream)), "hipMallocAsync");
+}
+extern "C" ec_status ec_free_async(void* dptr, ec_stream stream) {
+    return dptr ? check_hip(hipFreeAsync(dptr, S(stream)), "hipFreeAsync") : EC_OK;
+}
 
 extern "C" ec_status ec_upload(void* dst_dev, const void* src_host, size_t bytes, ec_stream stream) {
     if (bytes == 0) return EC_OK;

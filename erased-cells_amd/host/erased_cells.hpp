@@ -222,20 +222,20 @@ inline CellValue max_value(CellType ct) { ec_value v; check(ec_max_value(static_
 // ---------------------------------------------------------------- device plumbing
 inline void init(int device = 0) { check(ec_init(device)); }
 
-class DeviceMem {  // one HBM allocation
+inline ec_stream& current_stream() { static thread_local ec_stream s = nullptr; return s; }
+
+class DeviceMem {  // one HBM allocation, from the stream-ordered pool (no hipMalloc/hipFree per operator)
     void* p_ = nullptr;
     size_t bytes_ = 0;
 
 public:
-    explicit DeviceMem(size_t bytes) : bytes_(bytes) { check(ec_alloc(&p_, bytes)); }
-    ~DeviceMem() { if (p_) ec_free(p_); }
+    explicit DeviceMem(size_t bytes) : bytes_(bytes) { check(ec_alloc_async(&p_, bytes, current_stream())); }
+    ~DeviceMem() { if (p_) ec_free_async(p_, current_stream()); }
     DeviceMem(const DeviceMem&) = delete;
     DeviceMem& operator=(const DeviceMem&) = delete;
     void* ptr() const { return p_; }
     size_t bytes() const { return bytes_; }
 };
-
-inline ec_stream& current_stream() { static thread_local ec_stream s = nullptr; return s; }
 
 // ---------------------------------------------------------------- NoData<T> (src/masked/nodata.rs)
 template <typename T>

@@ -53,6 +53,8 @@ SIGNATURES = {
     "ec_device_info": (I32, [C.POINTER(I32), C.POINTER(C.c_uint64), C.c_char_p, SZ]),
     "ec_alloc": (I32, [C.POINTER(VP), SZ]),
     "ec_free": (I32, [VP]),
+    "ec_alloc_async": (I32, [C.POINTER(VP), SZ, VP]),
+    "ec_free_async": (I32, [VP, VP]),
     "ec_upload": (I32, [VP, VP, SZ, VP]),
     "ec_download": (I32, [VP, VP, SZ, VP]),
     "ec_copy": (I32, [VP, VP, SZ, VP]),

@@ -169,7 +169,7 @@ class DeviceMem:
             self._owned = False
         else:
             p = C.c_void_p()
-            check(lib().ec_alloc(C.byref(p), nbytes))
+            check(lib().ec_alloc_async(C.byref(p), nbytes, _stream))  # stream-ordered pool: no per-op hipMalloc
             self.ptr = p.value
             self._owned = True
 
@@ -180,7 +180,7 @@ class DeviceMem:
     def __del__(self):
         if getattr(self, "_owned", False) and self.ptr:
             try:
-                lib().ec_free(self.ptr)
+                lib().ec_free_async(self.ptr, _stream)
             except Exception:
                 pass
             self.ptr = None

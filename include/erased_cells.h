@@ -107,6 +107,12 @@ ec_status ec_device_info(int32_t *n_cu, uint64_t *hbm_bytes, char *name, size_t 
 
 ec_status ec_alloc(void **dptr, size_t bytes);
 ec_status ec_free(void *dptr);
+/* Stream-ordered allocation from the device's memory pool (hipMallocAsync / hipFreeAsync): what the host
+ * mirrors use for operator results, which the reference allocates per call (`collect()`,
+ * src/buffer.rs:327).  A block may be used by work enqueued on `stream` after the call, and freed
+ * blocks are recycled without synchronising the device. */
+ec_status ec_alloc_async(void **dptr, size_t bytes, ec_stream stream);
+ec_status ec_free_async(void *dptr, ec_stream stream);
 ec_status ec_upload(void *dst_dev, const void *src_host, size_t bytes, ec_stream stream);   /* From<Vec<T>> */
 ec_status ec_download(void *dst_host, const void *src_dev, size_t bytes, ec_stream stream); /* to_vec; waits for completion */
 ec_status ec_copy(void *dst_dev, const void *src_dev, size_t bytes, ec_stream stream);      /* Clone (buffer.rs:151-153) */
