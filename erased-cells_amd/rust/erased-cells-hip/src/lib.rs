@@ -42,12 +42,13 @@ fn check(st: ec_status) -> Result<()> {
     Err(Error::Backend(unsafe { CStr::from_ptr(ec_last_error_string()) }.to_string_lossy().into_owned()))
 }
 
-/// One HBM allocation; freed on drop.
+/// One HBM allocation from the stream-ordered pool (operator results are allocated per call, as the
+/// reference `collect()`s a fresh Vec; hipMalloc/hipFree per operator would cost as much as the kernel).
 struct DeviceMem(*mut c_void);
 impl DeviceMem {
-    fn new(bytes: usize) -> Result<Self> { let mut p = ptr::null_mut(); check(unsafe { ec_alloc(&mut p, bytes) })?; Ok(Self(p)) }
+    fn new(bytes: usize) -> Result<Self> { let mut p = ptr::null_mut(); check(unsafe { ec_alloc_async(&mut p, bytes, ptr::null_mut()) })?; Ok(Self(p)) }
 }
-impl Drop for DeviceMem { fn drop(&mut self) { unsafe { ec_free(self.0) }; } }
+impl Drop for DeviceMem { fn drop(&mut self) { unsafe { ec_free_async(self.0, ptr::null_mut()) }; } }
 
 /// `CellBuffer` with its cells resident on the GPU.
 pub struct CellBuffer { ct: CellType, len: usize, mem: DeviceMem }
@@ -105,6 +106,23 @@ cb_bin_op!(Add, add, EC_ADD);
 cb_bin_op!(Sub, sub, EC_SUB);
 cb_bin_op!(Mul, mul, EC_MUL);
 cb_bin_op!(Div, div, EC_DIV);
+
+// impl Ord / PartialEq for CellBuffer (src/buffer.rs:373-436): decided on the device.
+impl PartialEq for CellBuffer {
+    fn eq(&self, other: &Self) -> bool { self.cmp(other) == std::cmp::Ordering::Equal }
+}
+impl Eq for CellBuffer {}
+impl PartialOrd for CellBuffer {
+    fn partial_cmp(&self, other: &Self) -> Option<std::cmp::Ordering> { Some(self.cmp(other)) }
+}
+impl Ord for CellBuffer {
+    fn cmp(&self, other: &Self) -> std::cmp::Ordering {
+        let mut o = 0i32;
+        check(unsafe { ec_buffer_cmp(self.ct as u8, self.mem.0, self.len, other.ct as u8, other.mem.0, other.len, &mut o, ptr::null_mut()) })
+            .expect("ec_buffer_cmp");
+        o.cmp(&0)
+    }
+}
 
 impl Neg for &CellBuffer {
     type Output = CellBuffer;
