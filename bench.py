@@ -8,7 +8,7 @@ is cut into N contiguous row-blocks (one process / GPU); the divide
 needs no data-path collective.  Scaling is therefore "strong": the raster is
 fixed at 16384² (north_star) and each rank owns rows/N of it.
 
-  python bench.py --gpus 1 --steps 200 --warmup 60
+  python bench.py --gpus 1 --steps 200 --warmup 20
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -41,10 +41,8 @@ METRIC = "Gcells/s + HBM-GB/s roofline %, u8/u16->f64 16384^2, 1/2/4/8 GPUs"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: the first ~50 launches (≈25 ms) after idle run ≈5 % slow while the clocks ramp
-    # (profiles/r01/warmup_sensitivity.txt), so warm up past that by default
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--side", type=int, default=16384, help="raster is side x side cells")
     ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax", "ndvi"])
     ap.add_argument("--fused", action="store_true", help="masked_chain / ndvi: the single-pass fused kernel instead of the eager chain")
@@ -55,8 +53,8 @@ def parse():
                     help="torch.distributed backend; nccl (= RCCL over xGMI) is the product path, gloo only for rehearsals")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses device 0 (implies nothing about scaling)")
-    ap.add_argument("--ramp", type=int, default=60,
-                    help="minimum untimed launches before timing (clock ramp); extra ones beyond --warmup are reported")
+    ap.add_argument("--ramp", type=int, default=60, help="minimum untimed clock-ramp launches before the warm-up (0 = none)")
+    ap.add_argument("--ramp-ms", type=float, default=40.0, help="minimum wall time of the clock ramp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true",
                     help="also time from_vec (H2D) + divide + to_vec (D2H) once; reported beside, never as `value`")
@@ -255,11 +253,18 @@ def main():
         wl = wl.replace("eager", "fused")
 
     # ---- clock ramp + warm-up, then EXACTLY `steps` timed steps between barrier+synchronize.
-    # The first ≈50 launches after idle run ≈5 % slow while the GPU's clocks ramp
-    # (profiles/r01/warmup_sensitivity.txt); if the caller asks for fewer warm-up steps than that, the
-    # difference is run first as untimed, disclosed ramp steps (config.clock_ramp_steps).
-    ramp = max(0, args.ramp - args.warmup)
-    for _ in range(ramp + args.warmup):
+    # The first ≈25 ms of launches after idle run ≈5 % slow while the GPU's clocks ramp
+    # (profiles/r01/warmup_sensitivity.txt).  Untimed ramp launches run first until both --ramp launches
+    # and --ramp-ms of wall time have passed (a 1/8 shard's step is only ≈60 µs); their number is
+    # disclosed as config.clock_ramp_steps.  Then the W warm-up steps the caller asked for.
+    ramp = 0
+    t_ramp = time.perf_counter()
+    while args.ramp > 0 and (ramp < args.ramp or (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms):
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        ramp += 20
+    for _ in range(args.warmup):
         step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
