@@ -14,11 +14,12 @@
 //           each lane reads back the two cells that belong to each 16-B output
 //           slot and widens them ("LDS staging for the widening step").  The slab
 //           is private to the wave, so no workgroup barrier is needed.
-// One workgroup per tile of U chunks per wave, straight-line code, grid = number
-// of tiles (≫ 256 CUs: 65,536 workgroups at 16384²).  Loads and stores are
-// non-temporal: every byte is touched once and the streams (2.95 GB) dwarf the
-// 256 MiB Infinity Cache.  There is no reuse between workgroups (each 128-B line
-// is touched by exactly one wave), so no XCD-aware remap is needed for L2 locality.
+// One workgroup per tile of U = 2 chunks per wave (1,024 cells), straight-line code,
+// grid = number of tiles (≫ 256 CUs: 262,144 workgroups at 16384²), dealt from both
+// ends of the buffer at once (two_front_tile).  Loads and stores are non-temporal:
+// every byte is touched once and the streams (2.95 GB) dwarf the 256 MiB Infinity
+// Cache.  There is no reuse between workgroups (each 128-B line is touched by exactly
+// one wave), so an XCD-aware remap has no L2 locality to win (measured: −4 %).
 #pragma once
 
 #include "ec_device.hpp"
@@ -41,11 +42,6 @@ __device__ __forceinline__ V load_vec(const V* p) {
     else return *p;
 }
 
-
-// ---------------------------------------------------------------------------
-// DIRECT variant. Grid-stride over block tiles of kBlock*U pairs (2 cells each).
-// Requires l, r, out aligned to 2*sizeof(elem) / 16 B; the launcher checks.
-// ---------------------------------------------------------------------------
 // Workgroup -> tile map: even workgroups walk the buffer from the front, odd ones from the back, so
 // two streaming fronts are live at once (measured +1…5 % over a single front, tune_binop_v4/v5.log).
 // A bijection on [0, gridDim.x) for any grid size.
@@ -54,7 +50,10 @@ __device__ __forceinline__ size_t two_front_tile() {
     return (b & 1) ? size_t(gridDim.x) - 1 - (b >> 1) : (b >> 1);
 }
 
-// One block tile of the DIRECT variant.
+// ---------------------------------------------------------------------------
+// DIRECT variant: one block tile of kBlock*U pairs (2 cells each).  All pointers
+// 16-B aligned (the launcher checks, else the cell-wise kernel runs).
+// ---------------------------------------------------------------------------
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const R* __restrict__ r,
                                                   double* __restrict__ out, size_t npairs, size_t tile) {
