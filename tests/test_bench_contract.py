@@ -1,0 +1,45 @@
+"""bench.py's output contract: ONE JSON line on stdout with BASELINE.json's metric plus the
+`roofline` and `cpu_baseline` objects; and a loud failure (no fallback) without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
+    r = subprocess.run([sys.executable, BENCH, "--side", "4096", "--steps", "10", "--warmup", "2", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "Gcells/s"
+    for k, t in (("value", float), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[k], t), k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["cells"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert abs(rf["achieved"] - 11 * rf["cells_per_launch"] / (rf["launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert 0.05 < rf["frac"] < 1.0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Gcells/s" and cb["value"] > 0 and cb["sample"]
