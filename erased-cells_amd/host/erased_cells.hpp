@@ -23,6 +23,7 @@
 // by value / rvalue; Clone is explicit (`clone()`), copies are deleted.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -584,5 +585,56 @@ public:
 EC_MCB_OP(+, EC_ADD) EC_MCB_OP(-, EC_SUB) EC_MCB_OP(*, EC_MUL) EC_MCB_OP(/, EC_DIV)
 #undef EC_MCB_OP
 inline MaskedCellBuffer operator-(const MaskedCellBuffer& b) { return b.neg(); }
+
+// ---------------------------------------------------------------- fused operator chains
+// The reference evaluates `(&nir - &red) / (nir + red)` (src/gdal/rasterband.rs:148) eagerly, one pass and
+// one f64 temporary per operator.  `lazy(buf)` wraps a buffer so that the same operator syntax builds a
+// two-level expression which `eval()` runs as ONE kernel (ec_fused); every step is the same rounded f64
+// op, so the result is bit-identical to the eager chain.
+namespace fused {
+
+inline CellBuffer expr(const CellBuffer& x, ec_op o1, const CellBuffer& y, ec_op o2, const CellBuffer& z,
+                       ec_op o3 = EC_OP_NONE, const CellBuffer* w = nullptr) {
+    size_t n = std::min(std::min(x.len(), y.len()), z.len());
+    if (o3 != EC_OP_NONE) n = std::min(n, w->len());  // zip truncation of every step (buffer.rs:327)
+    if (n == 0) return CellBuffer(CellType::UInt8, 0);
+    const ec_dtype dt[4] = {static_cast<ec_dtype>(x.cell_type()), static_cast<ec_dtype>(y.cell_type()),
+                            static_cast<ec_dtype>(z.cell_type()), static_cast<ec_dtype>(w ? w->cell_type() : z.cell_type())};
+    const void* p[4] = {x.ptr(), y.ptr(), z.ptr(), w ? w->ptr() : nullptr};
+    CellBuffer out(CellType::Float64, n);
+    check(ec_fused(o1, o2, o3, dt, p, n, static_cast<double*>(out.ptr()), current_stream()));
+    return out;
+}
+inline MaskedCellBuffer expr(const MaskedCellBuffer& x, ec_op o1, const MaskedCellBuffer& y, ec_op o2, const MaskedCellBuffer& z,
+                             ec_op o3 = EC_OP_NONE, const MaskedCellBuffer* w = nullptr) {
+    size_t n = std::min(std::min(x.len(), y.len()), z.len());
+    if (o3 != EC_OP_NONE) n = std::min(n, w->len());
+    if (n == 0) return MaskedCellBuffer(CellBuffer(CellType::UInt8, 0), Mask(0));
+    const ec_dtype dt[4] = {static_cast<ec_dtype>(x.cell_type()), static_cast<ec_dtype>(y.cell_type()),
+                            static_cast<ec_dtype>(z.cell_type()), static_cast<ec_dtype>(w ? w->cell_type() : z.cell_type())};
+    const void* p[4] = {x.buffer().ptr(), y.buffer().ptr(), z.buffer().ptr(), w ? w->buffer().ptr() : nullptr};
+    const uint8_t* m[4] = {x.mask().ptr(), y.mask().ptr(), z.mask().ptr(), w ? w->mask().ptr() : nullptr};
+    CellBuffer out(CellType::Float64, n);
+    Mask om(n);
+    check(ec_masked_fused(o1, o2, o3, dt, p, m, n, static_cast<double*>(out.ptr()), om.ptr(), current_stream()));
+    return MaskedCellBuffer(std::move(out), std::move(om));
+}
+template <typename B> inline B ndvi(const B& nir, const B& red) { return expr(nir, EC_SUB, red, EC_DIV, nir, EC_ADD, &red); }
+
+// expression-template front end: lazy(a) - lazy(b) etc.
+template <typename B> struct Leaf { const B* b; };
+template <typename B> struct Node { const B* l; const B* r; ec_op op; };                                  // leaf op leaf
+template <typename B> struct Tree { Node<B> l; ec_op op; const B* rl; const B* rr; ec_op rop; };           // node op (leaf | node)
+template <typename B> inline Leaf<B> lazy(const B& b) { return Leaf<B>{&b}; }
+#define EC_LAZY_OP(SYM, OPC)                                                                                             \
+    template <typename B> inline Node<B> operator SYM(Leaf<B> a, Leaf<B> b) { return Node<B>{a.b, b.b, OPC}; }           \
+    template <typename B> inline Tree<B> operator SYM(Node<B> a, Leaf<B> b) { return Tree<B>{a, OPC, b.b, nullptr, EC_OP_NONE}; } \
+    template <typename B> inline Tree<B> operator SYM(Node<B> a, Node<B> b) { return Tree<B>{a, OPC, b.l, b.r, b.op}; }
+EC_LAZY_OP(+, EC_ADD) EC_LAZY_OP(-, EC_SUB) EC_LAZY_OP(*, EC_MUL) EC_LAZY_OP(/, EC_DIV)
+#undef EC_LAZY_OP
+template <typename B> inline B eval(const Node<B>& n) { return n.l->binop(n.op, *n.r); }
+template <typename B> inline B eval(const Tree<B>& t) { return expr(*t.l.l, t.l.op, *t.l.r, t.op, *t.rl, t.rop, t.rr); }
+
+}  // namespace fused
 
 }  // namespace erased_cells

@@ -360,6 +360,21 @@ static void gdal_tests(const std::string& data_dir) {
         }
         CHECK(row0 == rows && total_nodata == 4);
     }
+    {  // fused single-pass chains == the eager chains, bit for bit
+        using fused::lazy;
+        CellBuffer red = RasterBand::open(path("L8-Elkton-VA-B4.tiff")).read_cells();
+        CellBuffer nir = RasterBand::open(path("L8-Elkton-VA-B5.tiff")).read_cells();
+        CellBuffer eager = (nir - red) / (nir + red);
+        CHECK(fused::ndvi(nir, red) == eager);
+        CHECK(fused::eval((lazy(nir) - lazy(red)) / (lazy(nir) + lazy(red))) == eager);
+        CellBuffer r32 = red.convert(CellType::Float32);
+        CHECK(fused::eval((lazy(nir) + lazy(r32)) * lazy(red)) == (nir + r32) * red);
+        CHECK(fused::eval(lazy(nir) * lazy(r32)) == nir * r32);
+        MaskedCellBuffer mred = RasterBand::open(path("L8-Elkton-VA-B4.tiff")).read_cells_masked();
+        MaskedCellBuffer mnir = RasterBand::open(path("L8-Elkton-VA-B5-nd.tiff")).read_cells_masked();
+        MaskedCellBuffer mf = fused::eval((lazy(mnir) - lazy(mred)) / (lazy(mnir) + lazy(mred)));
+        CHECK(mf == (mnir - mred) / (mnir + mred) && mf.counts().second == 4);
+    }
     // GdalND -> NoData<T> (src/gdal/mod.rs:49-70): range-checked
     CHECK(!nodata_from_f64<uint16_t>(std::nullopt, "u16").value().has_value());
     CHECK(nodata_from_f64<uint16_t>(0.0, "u16").value() == uint16_t(0));
