@@ -208,7 +208,7 @@ def main():
         m4 = (C.c_void_p * 4)(masks[0].mem.ptr, masks[1].mem.ptr, masks[2].mem.ptr, None)
 
         def step_fused():
-            chk(L.ec_masked_fused(ec.ADD, ec.MUL, -1, dt4, p4, m4, n, out.mem.ptr, m2.mem.ptr, stream))
+            chk(L.ec_masked_fused(ec.ADD, ec.MUL, -1, dt4, p4, m4, None, n, out.mem.ptr, m2.mem.ptr, stream))
 
         def step():
             chk(L.ec_masked_binop(ec.ADD, ec.Float32, bufs[0].mem.ptr, masks[0].mem.ptr, ec.Float32, bufs[1].mem.ptr,
@@ -226,7 +226,7 @@ def main():
             p4 = (C.c_void_p * 4)(nir.mem.ptr, red.mem.ptr, nir.mem.ptr, red.mem.ptr)
 
             def step():
-                chk(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, n, out.mem.ptr, stream))
+                chk(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, None, n, out.mem.ptr, stream))
         else:
             bytes_per_cell, kernel = 48, "k_binop_direct Sub + Add (u16,u16) + Div (f64,f64): eager, 3 passes"
 

@@ -8,7 +8,8 @@
 using namespace ecd;
 
 static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], const void* const p[4],
-                              const uint8_t* const masks[4], size_t n, double* out, uint8_t* out_mask, hipStream_t s) {
+                              const uint8_t* const masks[4], const ec_value* scalars, size_t n, double* out,
+                              uint8_t* out_mask, hipStream_t s) {
     const int nops = o3 == kOpNone ? 3 : 4;
     auto op_ok = [](int o) { return o >= EC_ADD && o <= EC_DIV; };
     if (!op_ok(o1) || !op_ok(o2) || !(o3 == kOpNone || op_ok(o3))) return set_error(EC_ERR_ARG, "ec_fused: bad op");
@@ -18,22 +19,32 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
     fa.o2 = static_cast<int8_t>(o2);
     fa.o3 = static_cast<int8_t>(o3);
     bool aligned = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    int first_buf = -1;
     for (int k = 0; k < 4; ++k) {
         const int src = k < nops ? k : 2;  // unused w mirrors z
+        fa.alias[k] = static_cast<int8_t>(k);
+        if (!p[src]) {  // scalar operand (impl $trt<R: Into<CellValue>>, src/buffer.rs:346-352): widened to f64 once, here
+            if (!scalars || !ecl::valid(scalars[src].dtype)) return set_error(EC_ERR_ARG, "ec_fused: operand %d is neither a buffer nor a scalar", src);
+            fa.is_sc[k] = 1;
+            fa.sc[k] = ec_value_to_f64(&scalars[src]);
+            fa.dt[k] = EC_F64;
+            continue;
+        }
         if (!ecl::valid(dt[src])) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_fused: bad dtype of operand %d", src);
-        if (!p[src]) return set_error(EC_ERR_ARG, "ec_fused: null operand %d", src);
+        if (first_buf < 0) first_buf = k;
         fa.p[k] = p[src];
         fa.dt[k] = static_cast<int8_t>(dt[src]);
-        fa.alias[k] = static_cast<int8_t>(k);
         for (int j = 0; j < k; ++j)
-            if (fa.p[j] == fa.p[k] && fa.dt[j] == fa.dt[k]) { fa.alias[k] = static_cast<int8_t>(j); break; }
+            if (!fa.is_sc[j] && fa.p[j] == fa.p[k] && fa.dt[j] == fa.dt[k]) { fa.alias[k] = static_cast<int8_t>(j); break; }
         aligned = aligned && (reinterpret_cast<uintptr_t>(fa.p[k]) & 15u) == 0;
     }
+    if (first_buf < 0) return set_error(EC_ERR_ARG, "ec_fused: at least one operand must be a buffer");
     fa.nmask = 0;
     if (masks) {
         if (!out_mask) return set_error(EC_ERR_ARG, "ec_masked_fused: null out_mask");
         aligned = aligned && (reinterpret_cast<uintptr_t>(out_mask) & 15u) == 0;
         for (int k = 0; k < nops; ++k) {
+            if (fa.is_sc[k]) continue;  // a scalar carries no mask (masked_buffer.rs:353-364)
             if (!masks[k]) return set_error(EC_ERR_ARG, "ec_masked_fused: null mask %d", k);
             bool seen = false;
             for (int j = 0; j < fa.nmask; ++j) seen = seen || fa.m[j] == masks[k];
@@ -45,9 +56,10 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
     }
     if (aligned) {
         const size_t tiles = ((n >> 1) + size_t(kBlock) * kFusedU - 1) / (size_t(kBlock) * kFusedU);
-        const bool same = fa.dt[0] == fa.dt[1] && fa.dt[0] == fa.dt[2] && fa.dt[0] == fa.dt[3];
+        bool same = true;  // all buffer operands of one cell type?
+        for (int k = 0; k < 4; ++k) same = same && (fa.is_sc[k] || fa.dt[k] == fa.dt[first_buf]);
         if (same) {
-            switch (fa.dt[0]) {
+            switch (fa.dt[first_buf]) {
 #define EC_ROW(ID, T) case ID: k_fused_same<T><<<grid_for(tiles), kBlock, 0, s>>>(fa, out, out_mask, n); break;
                 EC_WITH_CT(EC_ROW)
 #undef EC_ROW
@@ -61,20 +73,20 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
     return check_launch("fused");
 }
 
-extern "C" ec_status ec_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void* const p[4], size_t n,
-                              double* out, ec_stream stream) {
+extern "C" ec_status ec_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void* const p[4],
+                              const ec_value* scalars_or_null, size_t n, double* out, ec_stream stream) {
     ec_status st = ensure_ready();
     if (st != EC_OK) return st;
     if (n == 0) return EC_OK;
-    return launch_fused(o1, o2, o3, dt, p, nullptr, n, out, nullptr, static_cast<hipStream_t>(stream));
+    return launch_fused(o1, o2, o3, dt, p, nullptr, scalars_or_null, n, out, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" ec_status ec_masked_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void* const p[4],
-                                     const uint8_t* const masks[4], size_t n, double* out, uint8_t* out_mask,
-                                     ec_stream stream) {
+                                     const uint8_t* const masks[4], const ec_value* scalars_or_null, size_t n, double* out,
+                                     uint8_t* out_mask, ec_stream stream) {
     ec_status st = ensure_ready();
     if (st != EC_OK) return st;
     if (n == 0) return EC_OK;
     if (!masks) return set_error(EC_ERR_ARG, "ec_masked_fused: null masks");
-    return launch_fused(o1, o2, o3, dt, p, masks, n, out, out_mask, static_cast<hipStream_t>(stream));
+    return launch_fused(o1, o2, o3, dt, p, masks, scalars_or_null, n, out, out_mask, static_cast<hipStream_t>(stream));
 }

@@ -31,6 +31,8 @@ struct FusedArgs {
     int8_t alias[4];         // alias[k] = j < k if operand k is the same buffer as operand j, else k
     int8_t o1, o2, o3;
     int8_t nmask;            // number of distinct masks to AND (0 = unmasked call)
+    int8_t is_sc[4];         // operand k is a scalar constant (no stream): value sc[k]
+    double sc[4];
 };
 
 // Operand reads are split in two so that all loads of a pair are in flight before the first use:
@@ -90,6 +92,10 @@ __device__ __forceinline__ double load_cell_f64(const void* p, int dt, size_t i)
     return 0.0;
 }
 
+__device__ __forceinline__ double operand_cell(const FusedArgs& fa, int k, size_t i) {
+    return fa.is_sc[k] ? fa.sc[k] : load_cell_f64(fa.p[k], fa.dt[k], i);
+}
+
 __device__ __forceinline__ double apply_rt(int op, double a, double b) {
     switch (op) {  // wave-uniform
         case EC_ADD: return cell_op<EC_ADD, true>(a, b);
@@ -142,16 +148,16 @@ __global__ __launch_bounds__(kBlock) void k_fused(FusedArgs fa, double* __restri
         const size_t pr = base + size_t(j) * kBlock;
         if (pr < npairs) {
             u32x4 raw[4] = {};
-            raw[0] = load_pair_raw(fa.p[0], fa.dt[0], pr);
-            if (fa.alias[1] == 1) raw[1] = load_pair_raw(fa.p[1], fa.dt[1], pr);
-            if (fa.alias[2] == 2) raw[2] = load_pair_raw(fa.p[2], fa.dt[2], pr);
-            if (has_w && fa.alias[3] == 3) raw[3] = load_pair_raw(fa.p[3], fa.dt[3], pr);
+            if (!fa.is_sc[0]) raw[0] = load_pair_raw(fa.p[0], fa.dt[0], pr);
+            if (!fa.is_sc[1] && fa.alias[1] == 1) raw[1] = load_pair_raw(fa.p[1], fa.dt[1], pr);
+            if (!fa.is_sc[2] && fa.alias[2] == 2) raw[2] = load_pair_raw(fa.p[2], fa.dt[2], pr);
+            if (has_w && !fa.is_sc[3] && fa.alias[3] == 3) raw[3] = load_pair_raw(fa.p[3], fa.dt[3], pr);
             D2 v[4];
-            v[0] = convert_pair(raw[0], fa.dt[0]);
-            v[1] = fa.alias[1] == 1 ? convert_pair(raw[1], fa.dt[1]) : v[0];
-            v[2] = fa.alias[2] == 2 ? convert_pair(raw[2], fa.dt[2]) : (fa.alias[2] == 0 ? v[0] : v[1]);
+            v[0] = fa.is_sc[0] ? D2{fa.sc[0], fa.sc[0]} : convert_pair(raw[0], fa.dt[0]);
+            v[1] = fa.is_sc[1] ? D2{fa.sc[1], fa.sc[1]} : fa.alias[1] == 1 ? convert_pair(raw[1], fa.dt[1]) : v[0];
+            v[2] = fa.is_sc[2] ? D2{fa.sc[2], fa.sc[2]} : fa.alias[2] == 2 ? convert_pair(raw[2], fa.dt[2]) : (fa.alias[2] == 0 ? v[0] : v[1]);
             v[3] = v[2];
-            if (has_w) v[3] = fa.alias[3] == 3 ? convert_pair(raw[3], fa.dt[3]) : (fa.alias[3] == 0 ? v[0] : fa.alias[3] == 1 ? v[1] : v[2]);
+            if (has_w) v[3] = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : fa.alias[3] == 3 ? convert_pair(raw[3], fa.dt[3]) : (fa.alias[3] == 0 ? v[0] : fa.alias[3] == 1 ? v[1] : v[2]);
             D2 o;
             o.x = fused_cell(fa, v[0].x, v[1].x, v[2].x, v[3].x);
             o.y = fused_cell(fa, v[0].y, v[1].y, v[2].y, v[3].y);
@@ -160,8 +166,8 @@ __global__ __launch_bounds__(kBlock) void k_fused(FusedArgs fa, double* __restri
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const size_t i = n - 1;
-        out[i] = fused_cell(fa, load_cell_f64(fa.p[0], fa.dt[0], i), load_cell_f64(fa.p[1], fa.dt[1], i),
-                            load_cell_f64(fa.p[2], fa.dt[2], i), has_w ? load_cell_f64(fa.p[3], fa.dt[3], i) : 0.0);
+        out[i] = fused_cell(fa, operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
+                            has_w ? operand_cell(fa, 3, i) : 0.0);
     }
     fused_mask_phase(fa, out_mask, n);
 }
@@ -186,10 +192,10 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
     for (int j = 0; j < kFusedU; ++j) {
         const size_t pr = base + size_t(j) * kBlock;
         if (pr < npairs) {
-            x[j] = __builtin_nontemporal_load(px + pr);
-            if (fa.alias[1] == 1) y[j] = __builtin_nontemporal_load(py + pr);
-            if (fa.alias[2] == 2) z[j] = __builtin_nontemporal_load(pz + pr);
-            if (has_w && fa.alias[3] == 3) w[j] = __builtin_nontemporal_load(pw + pr);
+            if (!fa.is_sc[0]) x[j] = __builtin_nontemporal_load(px + pr);
+            if (!fa.is_sc[1] && fa.alias[1] == 1) y[j] = __builtin_nontemporal_load(py + pr);
+            if (!fa.is_sc[2] && fa.alias[2] == 2) z[j] = __builtin_nontemporal_load(pz + pr);
+            if (has_w && !fa.is_sc[3] && fa.alias[3] == 3) w[j] = __builtin_nontemporal_load(pw + pr);
         }
     }
 #pragma unroll
@@ -199,16 +205,20 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
             const T2 yy = fa.alias[1] == 1 ? y[j] : x[j];
             const T2 zz = fa.alias[2] == 2 ? z[j] : (fa.alias[2] == 0 ? x[j] : yy);
             const T2 ww = !has_w ? zz : fa.alias[3] == 3 ? w[j] : (fa.alias[3] == 0 ? x[j] : fa.alias[3] == 1 ? yy : zz);
+            const D2 vx = fa.is_sc[0] ? D2{fa.sc[0], fa.sc[0]} : D2{to_f64(x[j].x), to_f64(x[j].y)};
+            const D2 vy = fa.is_sc[1] ? D2{fa.sc[1], fa.sc[1]} : D2{to_f64(yy.x), to_f64(yy.y)};
+            const D2 vz = fa.is_sc[2] ? D2{fa.sc[2], fa.sc[2]} : D2{to_f64(zz.x), to_f64(zz.y)};
+            const D2 vw = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : D2{to_f64(ww.x), to_f64(ww.y)};
             D2 o;
-            o.x = fused_cell(fa, to_f64(x[j].x), to_f64(yy.x), to_f64(zz.x), to_f64(ww.x));
-            o.y = fused_cell(fa, to_f64(x[j].y), to_f64(yy.y), to_f64(zz.y), to_f64(ww.y));
+            o.x = fused_cell(fa, vx.x, vy.x, vz.x, vw.x);
+            o.y = fused_cell(fa, vx.y, vy.y, vz.y, vw.y);
             __builtin_nontemporal_store(o, op + pr);
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const size_t i = n - 1;
-        out[i] = fused_cell(fa, load_cell_as<T>(fa.p[0], i), load_cell_as<T>(fa.p[1], i), load_cell_as<T>(fa.p[2], i),
-                            has_w ? load_cell_as<T>(fa.p[3], i) : 0.0);
+        out[i] = fused_cell(fa, operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
+                            has_w ? operand_cell(fa, 3, i) : 0.0);
     }
     fused_mask_phase(fa, out_mask, n);
 }
@@ -218,8 +228,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_cellwise(FusedArgs fa, double*
     const size_t stride = size_t(gridDim.x) * kBlock;
     const bool has_w = fa.o3 != kOpNone;
     for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
-        out[i] = fused_cell(fa, load_cell_f64(fa.p[0], fa.dt[0], i), load_cell_f64(fa.p[1], fa.dt[1], i),
-                            load_cell_f64(fa.p[2], fa.dt[2], i), has_w ? load_cell_f64(fa.p[3], fa.dt[3], i) : 0.0);
+        out[i] = fused_cell(fa, operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
+                            has_w ? operand_cell(fa, 3, i) : 0.0);
         if (fa.nmask > 0) {
             uint8_t acc = fa.m[0][i];
             for (int k = 1; k < fa.nmask; ++k) acc &= fa.m[k][i];

@@ -602,7 +602,19 @@ inline CellBuffer expr(const CellBuffer& x, ec_op o1, const CellBuffer& y, ec_op
                             static_cast<ec_dtype>(z.cell_type()), static_cast<ec_dtype>(w ? w->cell_type() : z.cell_type())};
     const void* p[4] = {x.ptr(), y.ptr(), z.ptr(), w ? w->ptr() : nullptr};
     CellBuffer out(CellType::Float64, n);
-    check(ec_fused(o1, o2, o3, dt, p, n, static_cast<double*>(out.ptr()), current_stream()));
+    check(ec_fused(o1, o2, o3, dt, p, nullptr, n, static_cast<double*>(out.ptr()), current_stream()));
+    return out;
+}
+// (x o1 y) o2 scalar — the RHS-scalar operator form (src/buffer.rs:346-352), e.g. `(buf + ones) * 2.0`
+inline CellBuffer expr(const CellBuffer& x, ec_op o1, const CellBuffer& y, ec_op o2, const CellValue& z) {
+    const size_t n = std::min(x.len(), y.len());
+    if (n == 0) return CellBuffer(CellType::UInt8, 0);
+    const ec_dtype dt[4] = {static_cast<ec_dtype>(x.cell_type()), static_cast<ec_dtype>(y.cell_type()), 0, 0};
+    const void* p[4] = {x.ptr(), y.ptr(), nullptr, nullptr};
+    ec_value sc[4] = {};
+    sc[2] = z.raw();
+    CellBuffer out(CellType::Float64, n);
+    check(ec_fused(o1, o2, EC_OP_NONE, dt, p, sc, n, static_cast<double*>(out.ptr()), current_stream()));
     return out;
 }
 inline MaskedCellBuffer expr(const MaskedCellBuffer& x, ec_op o1, const MaskedCellBuffer& y, ec_op o2, const MaskedCellBuffer& z,
@@ -616,7 +628,20 @@ inline MaskedCellBuffer expr(const MaskedCellBuffer& x, ec_op o1, const MaskedCe
     const uint8_t* m[4] = {x.mask().ptr(), y.mask().ptr(), z.mask().ptr(), w ? w->mask().ptr() : nullptr};
     CellBuffer out(CellType::Float64, n);
     Mask om(n);
-    check(ec_masked_fused(o1, o2, o3, dt, p, m, n, static_cast<double*>(out.ptr()), om.ptr(), current_stream()));
+    check(ec_masked_fused(o1, o2, o3, dt, p, m, nullptr, n, static_cast<double*>(out.ptr()), om.ptr(), current_stream()));
+    return MaskedCellBuffer(std::move(out), std::move(om));
+}
+inline MaskedCellBuffer expr(const MaskedCellBuffer& x, ec_op o1, const MaskedCellBuffer& y, ec_op o2, const CellValue& z) {
+    const size_t n = std::min(x.len(), y.len());
+    if (n == 0) return MaskedCellBuffer(CellBuffer(CellType::UInt8, 0), Mask(0));
+    const ec_dtype dt[4] = {static_cast<ec_dtype>(x.cell_type()), static_cast<ec_dtype>(y.cell_type()), 0, 0};
+    const void* p[4] = {x.buffer().ptr(), y.buffer().ptr(), nullptr, nullptr};
+    const uint8_t* m[4] = {x.mask().ptr(), y.mask().ptr(), nullptr, nullptr};
+    ec_value sc[4] = {};
+    sc[2] = z.raw();
+    CellBuffer out(CellType::Float64, n);
+    Mask om(n);
+    check(ec_masked_fused(o1, o2, EC_OP_NONE, dt, p, m, sc, n, static_cast<double*>(out.ptr()), om.ptr(), current_stream()));
     return MaskedCellBuffer(std::move(out), std::move(om));
 }
 template <typename B> inline B ndvi(const B& nir, const B& red) { return expr(nir, EC_SUB, red, EC_DIV, nir, EC_ADD, &red); }
@@ -632,6 +657,14 @@ template <typename B> inline Leaf<B> lazy(const B& b) { return Leaf<B>{&b}; }
     template <typename B> inline Tree<B> operator SYM(Node<B> a, Node<B> b) { return Tree<B>{a, OPC, b.l, b.r, b.op}; }
 EC_LAZY_OP(+, EC_ADD) EC_LAZY_OP(-, EC_SUB) EC_LAZY_OP(*, EC_MUL) EC_LAZY_OP(/, EC_DIV)
 #undef EC_LAZY_OP
+template <typename B> struct ScalarTree { Node<B> l; ec_op op; CellValue s; };                              // node op scalar
+#define EC_LAZY_SC(SYM, OPC)                                                                                             \
+    template <typename B> inline ScalarTree<B> operator SYM(Node<B> a, const CellValue& s) { return ScalarTree<B>{a, OPC, s}; } \
+    template <typename B, typename R, typename = decltype(CellEncoding<R>::cell_type())>                                 \
+    inline ScalarTree<B> operator SYM(Node<B> a, R s) { return ScalarTree<B>{a, OPC, CellValue(s)}; }
+EC_LAZY_SC(+, EC_ADD) EC_LAZY_SC(-, EC_SUB) EC_LAZY_SC(*, EC_MUL) EC_LAZY_SC(/, EC_DIV)
+#undef EC_LAZY_SC
+template <typename B> inline B eval(const ScalarTree<B>& t) { return expr(*t.l.l, t.l.op, *t.l.r, t.op, t.s); }
 template <typename B> inline B eval(const Node<B>& n) { return n.l->binop(n.op, *n.r); }
 template <typename B> inline B eval(const Tree<B>& t) { return expr(*t.l.l, t.l.op, *t.l.r, t.op, *t.rl, t.rop, t.rr); }
 

@@ -370,10 +370,12 @@ static void gdal_tests(const std::string& data_dir) {
         CellBuffer r32 = red.convert(CellType::Float32);
         CHECK(fused::eval((lazy(nir) + lazy(r32)) * lazy(red)) == (nir + r32) * red);
         CHECK(fused::eval(lazy(nir) * lazy(r32)) == nir * r32);
+        CHECK(fused::eval((lazy(nir) + lazy(red)) * 2.0) == (nir + red) * 2.0);  // examples/masked.rs:12 shape
         MaskedCellBuffer mred = RasterBand::open(path("L8-Elkton-VA-B4.tiff")).read_cells_masked();
         MaskedCellBuffer mnir = RasterBand::open(path("L8-Elkton-VA-B5-nd.tiff")).read_cells_masked();
         MaskedCellBuffer mf = fused::eval((lazy(mnir) - lazy(mred)) / (lazy(mnir) + lazy(mred)));
         CHECK(mf == (mnir - mred) / (mnir + mred) && mf.counts().second == 4);
+        CHECK(fused::eval((lazy(mnir) + lazy(mred)) * 2.0) == (mnir + mred) * 2.0);
     }
     // GdalND -> NoData<T> (src/gdal/mod.rs:49-70): range-checked
     CHECK(!nodata_from_f64<uint16_t>(std::nullopt, "u16").value().has_value());

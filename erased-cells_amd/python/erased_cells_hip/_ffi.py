@@ -65,8 +65,8 @@ SIGNATURES = {
     "ec_binop": (I32, [I32, C.c_uint8, VP, C.c_uint8, VP, SZ, VP, VP]),
     "ec_binop_scalar": (I32, [I32, C.c_uint8, VP, SZ, PV, VP, VP]),
     "ec_masked_binop": (I32, [I32, C.c_uint8, VP, U8P, C.c_uint8, VP, U8P, SZ, VP, U8P, VP]),
-    "ec_fused": (I32, [I32, I32, I32, C.POINTER(C.c_uint8), C.POINTER(VP), SZ, VP, VP]),
-    "ec_masked_fused": (I32, [I32, I32, I32, C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(VP), SZ, VP, U8P, VP]),
+    "ec_fused": (I32, [I32, I32, I32, C.POINTER(C.c_uint8), C.POINTER(VP), PV, SZ, VP, VP]),
+    "ec_masked_fused": (I32, [I32, I32, I32, C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(VP), PV, SZ, VP, U8P, VP]),
     "ec_neg": (I32, [C.c_uint8, VP, SZ, VP, VP]),
     "ec_convert": (I32, [C.c_uint8, VP, C.c_uint8, VP, SZ, VP]),
     "ec_fill": (I32, [C.c_uint8, VP, SZ, PV, VP]),

@@ -71,10 +71,11 @@ extern "C" {
     pub fn ec_mask_counts(m: *const u8, n: usize, n_true: *mut u64, n_false: *mut u64, s: ec_stream) -> ec_status;
     pub fn ec_buffer_cmp(lt: ec_dtype, l: *const c_void, nl: usize, rt: ec_dtype, r: *const c_void, nr: usize,
                          ordering: *mut i32, s: ec_stream) -> ec_status;
-    pub fn ec_fused(o1: ec_op, o2: ec_op, o3: ec_op, dt: *const ec_dtype, p: *const *const c_void, n: usize,
-                    out: *mut f64, s: ec_stream) -> ec_status;
+    pub fn ec_fused(o1: ec_op, o2: ec_op, o3: ec_op, dt: *const ec_dtype, p: *const *const c_void,
+                    scalars_or_null: *const ec_value, n: usize, out: *mut f64, s: ec_stream) -> ec_status;
     pub fn ec_masked_fused(o1: ec_op, o2: ec_op, o3: ec_op, dt: *const ec_dtype, p: *const *const c_void,
-                           masks: *const *const u8, n: usize, out: *mut f64, out_mask: *mut u8, s: ec_stream) -> ec_status;
+                           masks: *const *const u8, scalars_or_null: *const ec_value, n: usize, out: *mut f64,
+                           out_mask: *mut u8, s: ec_stream) -> ec_status;
     pub fn ec_allreduce_min_max_keys(rccl_comm: *mut c_void, keys2_dev: *mut i64, s: ec_stream) -> ec_status;
     pub fn ec_allreduce_counts(rccl_comm: *mut c_void, counts2_dev: *mut u64, s: ec_stream) -> ec_status;
     pub fn ec_shard_range(n_rows: u64, n_cols: u64, shard: u32, n_shards: u32, cell_offset: *mut u64,

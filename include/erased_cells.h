@@ -155,15 +155,18 @@ ec_status ec_fill(ec_dtype t, void *dst, size_t n, const ec_value *value, ec_str
  * chain of impl $trt for &CellBuffer (src/buffer.rs:324-329) performs, so the result is bit-identical
  * to evaluating the three operators one by one (e.g. NDVI `(&nir - &red) / (nir + red)`,
  * src/gdal/rasterband.rs:148) while the f64 temporaries never reach HBM.  o3 == EC_OP_NONE: the second
- * term is z alone (`(x o1 y) o2 z`, e.g. `(a + b) * c`) and dt[3]/p[3] are ignored.  Operands may alias. */
+ * term is z alone (`(x o1 y) o2 z`, e.g. `(a + b) * c`) and dt[3]/p[3] are ignored.  Operands may alias.
+ * An operand with p[k] == NULL is the scalar `scalars[k]` (the RHS-scalar form of src/buffer.rs:346-352,
+ * e.g. `(buf + ones) * 2.0`, examples/masked.rs:12); at least one operand must be a buffer; `n` is the
+ * shortest buffer operand's length. */
 #define EC_OP_NONE (-1)
-ec_status ec_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void *const p[4], size_t n,
-                   double *out, ec_stream stream);
-/* The masked form: also out_mask = AND of the operands' masks, as the eager chain of
- * impl $trt for &MaskedCellBuffer (src/masked/masked_buffer.rs:326-335) produces. */
+ec_status ec_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void *const p[4],
+                   const ec_value *scalars_or_null, size_t n, double *out, ec_stream stream);
+/* The masked form: also out_mask = AND of the buffer operands' masks, as the eager chain of
+ * impl $trt for &MaskedCellBuffer (src/masked/masked_buffer.rs:326-364) produces (a scalar has no mask). */
 ec_status ec_masked_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void *const p[4],
-                          const uint8_t *const masks[4], size_t n, double *out, uint8_t *out_mask,
-                          ec_stream stream);
+                          const uint8_t *const masks[4], const ec_value *scalars_or_null, size_t n,
+                          double *out, uint8_t *out_mask, ec_stream stream);
 
 /* ---------------------------------------------------------------- *
  * min/max under the reference's total order (ints natural; floats total_cmp),

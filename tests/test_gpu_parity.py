@@ -333,6 +333,18 @@ def test_fused_expression_equals_eager_chain(ec):
     assert ec.fused.ndvi(da.shard(0, 0), db).cell_type() == ec.UInt8  # empty chain -> UInt8 (buffer.rs:233-234)
     # zip truncation of every step
     assert ec.fused.add_mul(da, db.shard(0, 100), da).len() == 100
+    # scalar operands (the RHS-scalar operator form, src/buffer.rs:346-352), any position, any scalar type
+    for n in (1, 513, 20001):
+        x, y = rand_cells(eco.I16, n, 310), rand_cells(eco.F32, n, 311)
+        dx, dy = ec.CellBuffer.from_vec(x), ec.CellBuffer.from_vec(y)
+        got = ec.fused.expr(dx, ec.ADD, dy, ec.MUL, 2.0)                       # (x + y) * 2.0
+        assert np.array_equal(bits_of(got.to_numpy()), bits_of(((dx + dy) * 2.0).to_numpy()))
+        got = ec.fused.expr(dx, ec.MUL, np.float32(0.0001), ec.ADD, dy)        # x * scale + y
+        assert np.array_equal(bits_of(got.to_numpy()), bits_of(((dx * np.float32(0.0001)) + dy).to_numpy()))
+        got = ec.fused.expr(dx, ec.SUB, 7, ec.DIV, dx, ec.ADD, np.uint8(3))    # (x - 7) / (x + 3), aliased + scalars
+        assert np.array_equal(bits_of(got.to_numpy()), bits_of(((dx - 7) / (dx + np.uint8(3))).to_numpy()))
+        got = ec.fused.expr(dx, ec.DIV, dx, ec.MUL, dx, ec.SUB, 1.5)           # same-type fast path with a scalar
+        assert np.array_equal(bits_of(got.to_numpy()), bits_of(((dx / dx) * (dx - 1.5)).to_numpy()))
 
 
 def test_fused_masked_expression_equals_eager_chain(ec):
@@ -408,7 +420,7 @@ def test_streams_threads_and_graph_capture(ec):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=side):
         h = torch.cuda.current_stream().cuda_stream
-        ec._ffi.check(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, n, t_out.data_ptr(), h))
+        ec._ffi.check(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, None, n, t_out.data_ptr(), h))
         ec._ffi.check(L.ec_min_max_keys(ec.Float64, t_out.data_ptr(), None, n, t_keys.data_ptr(), h))
     for trial in range(2):
         if trial == 1:  # new inputs in the same buffers, same graph
