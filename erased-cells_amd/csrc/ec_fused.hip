@@ -5,6 +5,11 @@
 #include "ec_lattice.hpp"
 #include "ec_runtime.hpp"
 
+namespace ecd {
+template <int O2>
+void dispatch_fused(const FusedArgs& fa, int same_dt, unsigned grid, double* out, uint8_t* out_mask, size_t n, hipStream_t s);
+}
+
 using namespace ecd;
 
 static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], const void* const p[4],
@@ -58,17 +63,16 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         const size_t tiles = ((n >> 1) + size_t(kBlock) * kFusedU - 1) / (size_t(kBlock) * kFusedU);
         bool same = true;  // all buffer operands of one cell type?
         for (int k = 0; k < 4; ++k) same = same && (fa.is_sc[k] || fa.dt[k] == fa.dt[first_buf]);
-        if (same) {
-            switch (fa.dt[first_buf]) {
-#define EC_ROW(ID, T) case ID: k_fused_same<T><<<grid_for(tiles), kBlock, 0, s>>>(fa, out, out_mask, n); break;
-                EC_WITH_CT(EC_ROW)
-#undef EC_ROW
-            }
-        } else {
-            k_fused<<<grid_for(tiles), kBlock, 0, s>>>(fa, out, out_mask, n);
+        const int same_dt = same ? fa.dt[first_buf] : -1;
+        const unsigned grid = grid_for(tiles);
+        switch (o2) {
+            case EC_ADD: dispatch_fused<EC_ADD>(fa, same_dt, grid, out, out_mask, n, s); break;
+            case EC_SUB: dispatch_fused<EC_SUB>(fa, same_dt, grid, out, out_mask, n, s); break;
+            case EC_MUL: dispatch_fused<EC_MUL>(fa, same_dt, grid, out, out_mask, n, s); break;
+            default: dispatch_fused<EC_DIV>(fa, same_dt, grid, out, out_mask, n, s); break;
         }
     } else {
-        k_fused_cellwise<<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fa, out, out_mask, n);
+        k_fused_cellwise<0><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fa, out, out_mask, n);
     }
     return check_launch("fused");
 }

@@ -1,0 +1,3 @@
+// Fused expression kernels whose outer op is Add (see ec_fused_tu.hpp).
+#define EC_TU_OP EC_ADD
+#include "ec_fused_tu.hpp"

@@ -8,11 +8,11 @@
 //   NDVI on u16:      eager 12 + 12 + 24 = 48 B/cell  ->  fused 2 + 2 + 8 = 12 B/cell
 //   (a+b)*c f32+mask: eager 19 + 23 = 42 B/cell       ->  fused 4+4+4 + 8 + 3+1 = 24 B/cell
 //
-// Two kernels: `k_fused_same<T>` when all operands share one cell type (NDVI on u16 bands, the f32
-// chain of config 3): typed loads, all of a tile's loads in flight before the first use; and the
-// generic `k_fused`, where the operand cell types are run-time arguments read through wave-uniform
-// switches (raw load by width class, then conversion by type) — the "run-time typed loaders"
-// alternative to 10^4 template instantiations.  Ops are run-time in both (uniform switch).
+// Two kernels, both instantiated per op triple (80): `k_fused_same<T,...>` when all buffer operands
+// share one cell type (NDVI on u16 bands, the f32 chain of config 3): typed loads, all of a tile's
+// loads in flight before the first use; and the generic `k_fused<...>`, where the operand cell types
+// are run-time arguments read through wave-uniform switches (raw load by width class, then conversion
+// by type) — the "run-time typed loaders" alternative to 10^4 template instantiations.
 // Aliased operands (z == x, w == y for NDVI) are loaded once.
 #pragma once
 
@@ -105,13 +105,25 @@ __device__ __forceinline__ double apply_rt(int op, double a, double b) {
     }
 }
 
+// run-time ops (cell-wise fallback kernel only)
 __device__ __forceinline__ double fused_cell(const FusedArgs& fa, double x, double y, double z, double w) {
     const double t1 = apply_rt(fa.o1, x, y);
     const double t2 = fa.o3 == kOpNone ? z : apply_rt(fa.o3, z, w);
     return apply_rt(fa.o2, t1, t2);
 }
 
-constexpr int kFusedU = 2;
+// compile-time ops: a wave-uniform `switch` per cell costs ≈30 % on the NDVI kernel (it serialises the
+// four cells of a lane; tools/tune_fused.hip: 422 vs 546 Gcells/s), so the vector kernels are
+// instantiated per op triple (4 x 4 x 5 = 80) and only the operand TYPES stay run-time in k_fused.
+template <int O1, int O2, int O3>
+__device__ __forceinline__ double fused_cell_t(double x, double y, double z, double w) {
+    const double t1 = cell_op<O1, true>(x, y);
+    double t2 = z;
+    if constexpr (O3 != kOpNone) t2 = cell_op<O3, true>(z, w);
+    return cell_op<O2, true>(t1, t2);
+}
+
+constexpr int kFusedU = 4;  // pairs per lane per tile: the fused kernels carry more per-lane setup than k_binop_direct
 
 // mask phase: AND of the distinct operand masks (src/masked/masked_buffer.rs:333 applied per step),
 // 16 mask bytes per lane
@@ -136,12 +148,13 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
 
 
 // One workgroup per tile of kBlock*kFusedU pairs, two-front order, as k_binop_direct.
+template <int O1, int O2, int O3>
 __global__ __launch_bounds__(kBlock) void k_fused(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
     const size_t npairs = n >> 1;
     constexpr size_t TILE = size_t(kBlock) * kFusedU;
     const size_t tile = two_front_tile();
     const size_t base = tile * TILE + threadIdx.x;
-    const bool has_w = fa.o3 != kOpNone;
+    constexpr bool has_w = O3 != kOpNone;
     D2* __restrict__ op = reinterpret_cast<D2*>(out);
 #pragma unroll
     for (int j = 0; j < kFusedU; ++j) {
@@ -159,49 +172,53 @@ __global__ __launch_bounds__(kBlock) void k_fused(FusedArgs fa, double* __restri
             v[3] = v[2];
             if (has_w) v[3] = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : fa.alias[3] == 3 ? convert_pair(raw[3], fa.dt[3]) : (fa.alias[3] == 0 ? v[0] : fa.alias[3] == 1 ? v[1] : v[2]);
             D2 o;
-            o.x = fused_cell(fa, v[0].x, v[1].x, v[2].x, v[3].x);
-            o.y = fused_cell(fa, v[0].y, v[1].y, v[2].y, v[3].y);
+            o.x = fused_cell_t<O1, O2, O3>(v[0].x, v[1].x, v[2].x, v[3].x);
+            o.y = fused_cell_t<O1, O2, O3>(v[0].y, v[1].y, v[2].y, v[3].y);
             __builtin_nontemporal_store(o, op + pr);
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const size_t i = n - 1;
-        out[i] = fused_cell(fa, operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
-                            has_w ? operand_cell(fa, 3, i) : 0.0);
+        out[i] = fused_cell_t<O1, O2, O3>(operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
+                                          has_w ? operand_cell(fa, 3, i) : 0.0);
     }
     fused_mask_phase(fa, out_mask, n);
 }
 
 // All operands of one cell type T (NDVI on u16 bands, the f32 chain of config 3, ...): typed loads,
 // no per-operand dispatch.  Ops stay run-time (uniform switch).
-template <typename T>
+template <typename T, int O1, int O2, int O3>
 __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
     using T2 = vec<T, 2>;
     const size_t npairs = n >> 1;
     constexpr size_t TILE = size_t(kBlock) * kFusedU;
     const size_t tile = two_front_tile();
     const size_t base = tile * TILE + threadIdx.x;
-    const bool has_w = fa.o3 != kOpNone;
+    constexpr bool has_w = O3 != kOpNone;
     D2* __restrict__ op = reinterpret_cast<D2*>(out);
     const T2* __restrict__ px = static_cast<const T2*>(fa.p[0]);
     const T2* __restrict__ py = static_cast<const T2*>(fa.p[1]);
     const T2* __restrict__ pz = static_cast<const T2*>(fa.p[2]);
     const T2* __restrict__ pw = static_cast<const T2*>(fa.p[3]);
+    // launch-uniform operand configuration, resolved once per wave
+    const bool ld_x = !fa.is_sc[0], ld_y = !fa.is_sc[1] && fa.alias[1] == 1, ld_z = !fa.is_sc[2] && fa.alias[2] == 2,
+               ld_w = has_w && !fa.is_sc[3] && fa.alias[3] == 3;
+    const bool full = tile * TILE + TILE <= npairs;  // every pair of the tile exists: no per-pair guards
     T2 x[kFusedU] = {}, y[kFusedU] = {}, z[kFusedU] = {}, w[kFusedU] = {};
 #pragma unroll
     for (int j = 0; j < kFusedU; ++j) {
         const size_t pr = base + size_t(j) * kBlock;
-        if (pr < npairs) {
-            if (!fa.is_sc[0]) x[j] = __builtin_nontemporal_load(px + pr);
-            if (!fa.is_sc[1] && fa.alias[1] == 1) y[j] = __builtin_nontemporal_load(py + pr);
-            if (!fa.is_sc[2] && fa.alias[2] == 2) z[j] = __builtin_nontemporal_load(pz + pr);
-            if (has_w && !fa.is_sc[3] && fa.alias[3] == 3) w[j] = __builtin_nontemporal_load(pw + pr);
+        if (full || pr < npairs) {
+            if (ld_x) x[j] = __builtin_nontemporal_load(px + pr);
+            if (ld_y) y[j] = __builtin_nontemporal_load(py + pr);
+            if (ld_z) z[j] = __builtin_nontemporal_load(pz + pr);
+            if (ld_w) w[j] = __builtin_nontemporal_load(pw + pr);
         }
     }
 #pragma unroll
     for (int j = 0; j < kFusedU; ++j) {
         const size_t pr = base + size_t(j) * kBlock;
-        if (pr < npairs) {
+        if (full || pr < npairs) {
             const T2 yy = fa.alias[1] == 1 ? y[j] : x[j];
             const T2 zz = fa.alias[2] == 2 ? z[j] : (fa.alias[2] == 0 ? x[j] : yy);
             const T2 ww = !has_w ? zz : fa.alias[3] == 3 ? w[j] : (fa.alias[3] == 0 ? x[j] : fa.alias[3] == 1 ? yy : zz);
@@ -210,20 +227,22 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
             const D2 vz = fa.is_sc[2] ? D2{fa.sc[2], fa.sc[2]} : D2{to_f64(zz.x), to_f64(zz.y)};
             const D2 vw = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : D2{to_f64(ww.x), to_f64(ww.y)};
             D2 o;
-            o.x = fused_cell(fa, vx.x, vy.x, vz.x, vw.x);
-            o.y = fused_cell(fa, vx.y, vy.y, vz.y, vw.y);
+            o.x = fused_cell_t<O1, O2, O3>(vx.x, vy.x, vz.x, vw.x);
+            o.y = fused_cell_t<O1, O2, O3>(vx.y, vy.y, vz.y, vw.y);
             __builtin_nontemporal_store(o, op + pr);
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const size_t i = n - 1;
-        out[i] = fused_cell(fa, operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
-                            has_w ? operand_cell(fa, 3, i) : 0.0);
+        out[i] = fused_cell_t<O1, O2, O3>(operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
+                                          has_w ? operand_cell(fa, 3, i) : 0.0);
     }
     fused_mask_phase(fa, out_mask, n);
 }
 
-// Any alignment: one cell per lane.
+// Any alignment: one cell per lane, run-time ops.  (A template only so that the header can be included
+// by several translation units.)
+template <int UNUSED = 0>
 __global__ __launch_bounds__(kBlock) void k_fused_cellwise(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
     const size_t stride = size_t(gridDim.x) * kBlock;
     const bool has_w = fa.o3 != kOpNone;
