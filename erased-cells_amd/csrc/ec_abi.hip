@@ -303,7 +303,12 @@ extern "C" int32_t ec_abi_version(void) { return EC_ABI_VERSION; }
 
 extern "C" ec_status ec_init(int32_t device) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_inited && g_device == device) return EC_OK;
+    if (g_inited && g_device == device) {
+        if (t_bound_device != device && hipSetDevice(device) == hipSuccess) t_bound_device = device;
+        return EC_OK;
+    }
+    if (g_inited)  // one process per GPU: scratch and pooled memory belong to the bound device
+        return set_error(EC_ERR_ARG, "ec_init: already bound to device %d; call ec_shutdown() before binding device %d", g_device, device);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)

@@ -98,7 +98,8 @@ ec_status ec_shard_range(uint64_t n_rows, uint64_t n_cols, uint32_t shard, uint3
  * Runtime: device, memory, streams, errors.
  * ---------------------------------------------------------------- */
 int32_t ec_abi_version(void);
-ec_status ec_init(int32_t device);   /* binds the calling process to `device`; idempotent */
+ec_status ec_init(int32_t device);   /* binds the process to `device` (one process per GPU); idempotent for the
+                                        same device, EC_ERR_ARG for another one until ec_shutdown() */
 ec_status ec_shutdown(void);         /* frees reduction scratch */
 const char *ec_last_error_string(void);
 /* src/dst of the last EC_ERR_NARROWING on this thread (Error::NarrowingError fields). */
