@@ -367,6 +367,66 @@ def test_fused_masked_expression_equals_eager_chain(ec):
         assert got.counts() == exp.counts()
 
 
+def test_randomised_shapes_types_and_windows(ec):
+    """Property test (hypothesis): any type pair, op, length and pair of window offsets gives the oracle's
+    bits — exercises every vector/cell-wise path choice, tile boundary and ragged tail."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    pool = {ct: rand_cells(ct, 70000, 900 + ct) for ct in range(NT)}
+    dev = {ct: ec.CellBuffer.from_vec(a) for ct, a in pool.items()}
+    mpool = rand_mask(70000, 950)
+    dmask = ec.Mask.new(mpool)
+
+    @settings(max_examples=200, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(lt=st.integers(0, NT - 1), rt=st.integers(0, NT - 1), op=st.integers(0, 3),
+           n=st.one_of(st.integers(0, 40), st.integers(500, 1100), st.integers(4000, 4200), st.integers(60000, 65000)),
+           lo=st.sampled_from([0, 1, 2, 3, 5, 8, 16, 17, 32, 48, 64, 1000]),
+           ro=st.sampled_from([0, 1, 4, 7, 16, 31, 32, 64, 999]),
+           variant=st.integers(0, 1), kind=st.integers(0, 4))
+    def run(lt, rt, op, n, lo, ro, variant, kind):
+        l, r = pool[lt][lo:lo + n], pool[rt][ro:ro + n]
+        dl, dr = dev[lt].shard(lo, n), dev[rt].shard(ro, n)
+        ec.lib().ec_tune_set(b"binop_variant", variant)
+        if kind == 0:      # buffer op buffer
+            got = dl._binop(op, dr)
+            if n == 0:
+                assert got.cell_type() == ec.UInt8 and got.len() == 0
+                return
+            loose = _both_nan(l, r) if op in (eco.ADD, eco.MUL) else None
+            assert_f64_bits_equal(got.to_numpy(), eco.f_binop(op, l, r), nan_by_class_where=loose)
+        elif kind == 1:    # masked op masked (fused value + mask kernel)
+            ml = ec.MaskedCellBuffer(dl, dmask.shard(lo, n))
+            mr = ec.MaskedCellBuffer(dr, dmask.shard(ro, n))
+            got = ml._binop(op, mr)
+            if n:
+                loose = _both_nan(l, r) if op in (eco.ADD, eco.MUL) else None
+                assert_f64_bits_equal(got.buffer().to_numpy(), eco.f_binop(op, l, r), nan_by_class_where=loose)
+                assert np.array_equal(got.mask().to_numpy(), mpool[lo:lo + n] & mpool[ro:ro + n])
+        elif kind == 2:    # neg + min_max (masked)
+            if n:
+                assert np.array_equal(bits_of((-dl).to_numpy()), bits_of(eco.f_neg(l)))
+            mn, mx = ec.MaskedCellBuffer(dl, dmask.shard(ro, n)).min_max()
+            emn, emx = eco.f_min_max(l, mpool[ro:ro + n])
+            assert (mn.bits(), mx.bits()) == (emn.bits(), emx.bits())
+        elif kind == 3:    # convert (legal pairs) / narrowing error
+            if eco.can_fit_into(lt, rt):
+                got = dl.convert(rt)
+                if n and lt != rt:
+                    assert np.array_equal(bits_of(got.to_numpy()), bits_of(eco.f_convert(l, rt)))
+            else:
+                with pytest.raises(ec.NarrowingError):
+                    dl.convert(rt)
+        else:              # compare + mask from nodata
+            assert dl.cmp(dr) == eco.buffer_cmp(l, r)
+            nd = eco.nodata_value(eco.ND_DEFAULT, lt)
+            assert np.array_equal(ec.mask_from_nodata(dl, ec.NoData.default()).to_numpy(), eco.f_mask_from_nodata(l, nd))
+
+    try:
+        run()
+    finally:
+        ec.lib().ec_tune_set(b"binop_variant", 0)
+
+
 def test_streams_threads_and_graph_capture(ec):
     """Re-entrancy: concurrent host threads on distinct streams (per-stream reduction scratch, per-thread
     device binding), and a chain of asynchronous calls captured into a hipGraph and replayed."""
