@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--side", type=int, default=16384, help="raster is side x side cells")
     ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax", "ndvi"])
     ap.add_argument("--fused", action="store_true", help="masked_chain / ndvi: the single-pass fused kernel instead of the eager chain")
+    ap.add_argument("--mixed", action="store_true", help="ndvi: red band as f32 (mixed operand types -> the generic fused kernel)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: one side² raster row-sharded over the ranks (default); weak: side² per rank")
     ap.add_argument("--variant", type=int, default=None, help="binop kernel variant: 0 direct, 1 LDS-staged")
@@ -216,23 +217,24 @@ def main():
             chk(L.ec_masked_binop(ec.MUL, ec.Float64, t1.mem.ptr, m1.mem.ptr, ec.Float32, bufs[2].mem.ptr,
                                   masks[2].mem.ptr, n, out.mem.ptr, m2.mem.ptr, stream))
     elif args.workload == "ndvi":
-        nir, red = ec.CellBuffer.empty(n, ec.UInt16), ec.CellBuffer.empty(n, ec.UInt16)
+        red_t = ec.Float32 if args.mixed else ec.UInt16
+        nir, red = ec.CellBuffer.empty(n, ec.UInt16), ec.CellBuffer.empty(n, red_t)
         chk(L.ec_synth_fill(ec.UInt16, nir.mem.ptr, n, 0x5EED0007, off, 5000.0, 40000.0, stream))
-        chk(L.ec_synth_fill(ec.UInt16, red.mem.ptr, n, 0x5EED0008, off, 5000.0, 30000.0, stream))
+        chk(L.ec_synth_fill(red_t, red.mem.ptr, n, 0x5EED0008, off, 5000.0, 30000.0, stream))
         t1, t2, out = (ec.CellBuffer.empty(n, ec.Float64) for _ in range(3))
         if args.fused:
-            bytes_per_cell, kernel = 12, "k_fused (nir-red)/(nir+red) u16, one pass"
-            dt4 = (C.c_uint8 * 4)(ec.UInt16, ec.UInt16, ec.UInt16, ec.UInt16)
+            bytes_per_cell, kernel = (14 if args.mixed else 12), "k_fused (nir-red)/(nir+red), one pass"
+            dt4 = (C.c_uint8 * 4)(ec.UInt16, red_t, ec.UInt16, red_t)
             p4 = (C.c_void_p * 4)(nir.mem.ptr, red.mem.ptr, nir.mem.ptr, red.mem.ptr)
 
             def step():
                 chk(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, None, n, out.mem.ptr, stream))
         else:
-            bytes_per_cell, kernel = 48, "k_binop_direct Sub + Add (u16,u16) + Div (f64,f64): eager, 3 passes"
+            bytes_per_cell, kernel = (52 if args.mixed else 48), "k_binop_direct Sub + Add + Div (f64,f64): eager, 3 passes"
 
             def step():
-                chk(L.ec_binop(ec.SUB, ec.UInt16, nir.mem.ptr, ec.UInt16, red.mem.ptr, n, t1.mem.ptr, stream))
-                chk(L.ec_binop(ec.ADD, ec.UInt16, nir.mem.ptr, ec.UInt16, red.mem.ptr, n, t2.mem.ptr, stream))
+                chk(L.ec_binop(ec.SUB, ec.UInt16, nir.mem.ptr, red_t, red.mem.ptr, n, t1.mem.ptr, stream))
+                chk(L.ec_binop(ec.ADD, ec.UInt16, nir.mem.ptr, red_t, red.mem.ptr, n, t2.mem.ptr, stream))
                 chk(L.ec_binop(ec.DIV, ec.Float64, t1.mem.ptr, ec.Float64, t2.mem.ptr, n, out.mem.ptr, stream))
         wl = f"{side}x{side} u16 NDVI (nir-red)/(nir+red) (BASELINE configs[4] arithmetic at raster scale), " + ("fused" if args.fused else "eager")
     else:

@@ -1,4 +1,5 @@
-// ec_fused.hip — ABI entry points of the fused two-level expression kernel (ec_fused_kernels.hpp).
+// ec_fused.hip — ABI entry points of the fused two-level expression kernels (ec_fused_kernels.hpp):
+// operand set-up (aliases, scalars, masks), unification of mixed operand types, dispatch by op triple.
 #include <hip/hip_runtime.h>
 
 #include "ec_fused_kernels.hpp"
@@ -59,23 +60,48 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
             }
         }
     }
-    if (aligned) {
-        const size_t tiles = ((n >> 1) + size_t(kBlock) * kFusedU - 1) / (size_t(kBlock) * kFusedU);
-        bool same = true;  // all buffer operands of one cell type?
-        for (int k = 0; k < 4; ++k) same = same && (fa.is_sc[k] || fa.dt[k] == fa.dt[first_buf]);
-        const int same_dt = same ? fa.dt[first_buf] : -1;
-        const unsigned grid = grid_for(tiles);
-        switch (o2) {
-            case EC_ADD: dispatch_fused<EC_ADD>(fa, same_dt, grid, out, out_mask, n, s); break;
-            case EC_SUB: dispatch_fused<EC_SUB>(fa, same_dt, grid, out, out_mask, n, s); break;
-            case EC_MUL: dispatch_fused<EC_MUL>(fa, same_dt, grid, out, out_mask, n, s); break;
-            default: dispatch_fused<EC_DIV>(fa, same_dt, grid, out, out_mask, n, s); break;
-        }
-    } else {
+    if (!aligned) {
         k_fused_cellwise<0><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fa, out, out_mask, n);
+        return check_launch("fused(cellwise)");
     }
-    return check_launch("fused");
+    // Mixed operand types: widen every buffer operand to the common CellType::union first (the
+    // reference's `unify`, value-preserving — SURVEY App. A.1) into temporaries from the stream-ordered
+    // pool, then run the same-type kernel.  Same-type calls allocate nothing.
+    int u = fa.dt[first_buf];
+    for (int k = 0; k < 4; ++k)
+        if (!fa.is_sc[k]) u = ecl::union_of(u, fa.dt[k]);
+    void* temps[4] = {nullptr, nullptr, nullptr, nullptr};
+    ec_status st = EC_OK;
+    for (int k = 0; k < 4 && st == EC_OK; ++k) {
+        if (fa.is_sc[k] || fa.dt[k] == u) continue;
+        if (fa.alias[k] != k) {  // same buffer as an earlier operand: reuse its widened copy
+            fa.p[k] = fa.p[fa.alias[k]];
+            fa.dt[k] = static_cast<int8_t>(u);
+            continue;
+        }
+        st = ec_alloc_async(&temps[k], n * ecl::size_of(u), s);
+        if (st != EC_OK) break;
+        st = ec_convert(static_cast<ec_dtype>(fa.dt[k]), fa.p[k], static_cast<ec_dtype>(u), temps[k], n, s);
+        fa.p[k] = temps[k];
+        fa.dt[k] = static_cast<int8_t>(u);
+    }
+    if (st == EC_OK) {
+        const size_t per_tile = size_t(kBlock) * kFusedU;
+        const unsigned grid = grid_for(((n >> 1) + per_tile - 1) / per_tile);
+        switch (o2) {
+            case EC_ADD: dispatch_fused<EC_ADD>(fa, u, grid, out, out_mask, n, s); break;
+            case EC_SUB: dispatch_fused<EC_SUB>(fa, u, grid, out, out_mask, n, s); break;
+            case EC_MUL: dispatch_fused<EC_MUL>(fa, u, grid, out, out_mask, n, s); break;
+            default: dispatch_fused<EC_DIV>(fa, u, grid, out, out_mask, n, s); break;
+        }
+        st = check_launch("fused");
+    }
+    for (int k = 0; k < 4; ++k)
+        if (temps[k]) (void)ec_free_async(temps[k], s);  // stream-ordered: released after the kernel
+    return st;
 }
+
+
 
 extern "C" ec_status ec_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void* const p[4],
                               const ec_value* scalars_or_null, size_t n, double* out, ec_stream stream) {

@@ -8,12 +8,13 @@
 //   NDVI on u16:      eager 12 + 12 + 24 = 48 B/cell  ->  fused 2 + 2 + 8 = 12 B/cell
 //   (a+b)*c f32+mask: eager 19 + 23 = 42 B/cell       ->  fused 4+4+4 + 8 + 3+1 = 24 B/cell
 //
-// Two kernels, both instantiated per op triple (80): `k_fused_same<T,...>` when all buffer operands
-// share one cell type (NDVI on u16 bands, the f32 chain of config 3): typed loads, all of a tile's
-// loads in flight before the first use; and the generic `k_fused<...>`, where the operand cell types
-// are run-time arguments read through wave-uniform switches (raw load by width class, then conversion
-// by type) — the "run-time typed loaders" alternative to 10^4 template instantiations.
-// Aliased operands (z == x, w == y for NDVI) are loaded once.
+// The vector kernel `k_fused_same<T,O1,O2,O3>` handles buffer operands of ONE cell type (NDVI on u16
+// bands, the f32 chain of config 3), instantiated per type and op triple: typed loads, all of a tile's
+// loads in flight before the first use.  Operands of mixed types are first widened to their common
+// `CellType::union` (value-preserving: the reference's own `unify`, src/value.rs:103-107) by the
+// convert kernel into pooled temporaries — a kernel with run-time typed loaders was tried and ran at
+// 27 % of peak (the per-type branches serialise its loads), slower than convert + same-type fusion.
+// Aliased operands (z == x, w == y for NDVI) are loaded once; scalars cost no stream.
 #pragma once
 
 #include "ec_binop_kernels.hpp"
@@ -34,51 +35,6 @@ struct FusedArgs {
     int8_t is_sc[4];         // operand k is a scalar constant (no stream): value sc[k]
     double sc[4];
 };
-
-// Operand reads are split in two so that all loads of a pair are in flight before the first use:
-// (1) raw load by WIDTH class only (4 uniform cases, no conversion => no wait inside the branch),
-// (2) conversion of the raw bits by cell TYPE (10 uniform cases, registers only).
-__device__ __forceinline__ u32x4 load_pair_raw(const void* p, int dt, size_t pair) {
-    u32x4 r = {0, 0, 0, 0};
-    switch (dt) {
-        case EC_U8: case EC_I8:
-            r.x = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(p) + pair);
-            break;
-        case EC_U16: case EC_I16:
-            r.x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p) + pair);
-            break;
-        case EC_U32: case EC_I32: case EC_F32: {
-            const vec<uint32_t, 2> v = __builtin_nontemporal_load(reinterpret_cast<const vec<uint32_t, 2>*>(p) + pair);
-            r.x = v.x;
-            r.y = v.y;
-            break;
-        }
-        default:
-            r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + pair);
-            break;
-    }
-    return r;
-}
-
-__device__ __forceinline__ D2 convert_pair(u32x4 r, int dt) {
-    // scalars first: ROCm 7.2's hipcc folded `bit_cast<float>(r.y)` on the vector element to r.x
-    const uint32_t a = r.x, b = r.y, c = r.z, d = r.w;
-    const uint64_t q0 = a | (uint64_t(b) << 32), q1 = c | (uint64_t(d) << 32);
-    double lo, hi;
-    switch (dt) {
-        case EC_U8: lo = double(a & 0xFFu); hi = double((a >> 8) & 0xFFu); break;
-        case EC_I8: lo = double(int8_t(a)); hi = double(int8_t(a >> 8)); break;
-        case EC_U16: lo = double(a & 0xFFFFu); hi = double(a >> 16); break;
-        case EC_I16: lo = double(int16_t(a)); hi = double(int16_t(a >> 16)); break;
-        case EC_U32: lo = double(a); hi = double(b); break;
-        case EC_I32: lo = double(int32_t(a)); hi = double(int32_t(b)); break;
-        case EC_F32: lo = double(__uint_as_float(a)); hi = double(__uint_as_float(b)); break;
-        case EC_U64: lo = double(q0); hi = double(q1); break;
-        case EC_I64: lo = double(int64_t(q0)); hi = double(int64_t(q1)); break;
-        default: lo = __longlong_as_double(static_cast<long long>(q0)); hi = __longlong_as_double(static_cast<long long>(q1)); break;
-    }
-    return D2{lo, hi};
-}
 
 template <typename T>
 __device__ __forceinline__ double load_cell_as(const void* p, size_t i) { return to_f64(static_cast<const T*>(p)[i]); }
@@ -147,46 +103,8 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
 }
 
 
-// One workgroup per tile of kBlock*kFusedU pairs, two-front order, as k_binop_direct.
-template <int O1, int O2, int O3>
-__global__ __launch_bounds__(kBlock) void k_fused(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
-    const size_t npairs = n >> 1;
-    constexpr size_t TILE = size_t(kBlock) * kFusedU;
-    const size_t tile = two_front_tile();
-    const size_t base = tile * TILE + threadIdx.x;
-    constexpr bool has_w = O3 != kOpNone;
-    D2* __restrict__ op = reinterpret_cast<D2*>(out);
-#pragma unroll
-    for (int j = 0; j < kFusedU; ++j) {
-        const size_t pr = base + size_t(j) * kBlock;
-        if (pr < npairs) {
-            u32x4 raw[4] = {};
-            if (!fa.is_sc[0]) raw[0] = load_pair_raw(fa.p[0], fa.dt[0], pr);
-            if (!fa.is_sc[1] && fa.alias[1] == 1) raw[1] = load_pair_raw(fa.p[1], fa.dt[1], pr);
-            if (!fa.is_sc[2] && fa.alias[2] == 2) raw[2] = load_pair_raw(fa.p[2], fa.dt[2], pr);
-            if (has_w && !fa.is_sc[3] && fa.alias[3] == 3) raw[3] = load_pair_raw(fa.p[3], fa.dt[3], pr);
-            D2 v[4];
-            v[0] = fa.is_sc[0] ? D2{fa.sc[0], fa.sc[0]} : convert_pair(raw[0], fa.dt[0]);
-            v[1] = fa.is_sc[1] ? D2{fa.sc[1], fa.sc[1]} : fa.alias[1] == 1 ? convert_pair(raw[1], fa.dt[1]) : v[0];
-            v[2] = fa.is_sc[2] ? D2{fa.sc[2], fa.sc[2]} : fa.alias[2] == 2 ? convert_pair(raw[2], fa.dt[2]) : (fa.alias[2] == 0 ? v[0] : v[1]);
-            v[3] = v[2];
-            if (has_w) v[3] = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : fa.alias[3] == 3 ? convert_pair(raw[3], fa.dt[3]) : (fa.alias[3] == 0 ? v[0] : fa.alias[3] == 1 ? v[1] : v[2]);
-            D2 o;
-            o.x = fused_cell_t<O1, O2, O3>(v[0].x, v[1].x, v[2].x, v[3].x);
-            o.y = fused_cell_t<O1, O2, O3>(v[0].y, v[1].y, v[2].y, v[3].y);
-            __builtin_nontemporal_store(o, op + pr);
-        }
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const size_t i = n - 1;
-        out[i] = fused_cell_t<O1, O2, O3>(operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
-                                          has_w ? operand_cell(fa, 3, i) : 0.0);
-    }
-    fused_mask_phase(fa, out_mask, n);
-}
-
-// All operands of one cell type T (NDVI on u16 bands, the f32 chain of config 3, ...): typed loads,
-// no per-operand dispatch.  Ops stay run-time (uniform switch).
+// One workgroup per tile of kBlock*kFusedU pairs, two-front order, as k_binop_direct.  All buffer
+// operands have cell type T.
 template <typename T, int O1, int O2, int O3>
 __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
     using T2 = vec<T, 2>;

@@ -1,5 +1,5 @@
 // ec_fused_tu.hpp — launchers of the fused kernels for one outer op O2 (4 inner ops x 5 second-term
-// ops x 10 same-type kernels + the generic kernel); ec_fused_{add,sub,mul,div}.hip instantiate one each.
+// ops x 10 cell types); ec_fused_{add,sub,mul,div}.hip instantiate one each.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -15,7 +15,7 @@ static void launch_fused_ops(const FusedArgs& fa, int same_dt, unsigned grid, do
 #define EC_ROW(ID, T) case ID: k_fused_same<T, O1, O2, O3><<<grid, kBlock, 0, s>>>(fa, out, out_mask, n); return;
         EC_WITH_CT(EC_ROW)
 #undef EC_ROW
-        default: k_fused<O1, O2, O3><<<grid, kBlock, 0, s>>>(fa, out, out_mask, n); return;
+        default: return;  // unreachable: the caller unifies mixed operand types first
     }
 }
 
@@ -30,7 +30,7 @@ static void launch_fused_o3(const FusedArgs& fa, int same_dt, unsigned grid, dou
     }
 }
 
-// same_dt: the common cell type of all buffer operands, or -1 for mixed types (generic kernel)
+// same_dt: the common cell type of all buffer operands
 template <int O2>
 void dispatch_fused(const FusedArgs& fa, int same_dt, unsigned grid, double* out, uint8_t* out_mask, size_t n, hipStream_t s) {
     switch (fa.o1) {
