@@ -120,8 +120,9 @@ ec_status ec_copy(void *dst_dev, const void *src_dev, size_t bytes, ec_stream st
 ec_status ec_stream_create(ec_stream *out);
 /* Allocates the per-stream reduction scratch of a stream the library did not create (NULL = default
  * stream, a torch stream, ...).  After this, every asynchronous entry point — including ec_min_max_keys and
- * ec_mask_counts_device — performs no allocation and no synchronisation, so a chain of calls can be
- * captured into a hipGraph on that stream and replayed. */
+ * ec_mask_counts_device — performs no allocation and no synchronisation (ec_fused over mixed cell types
+ * excepted: it draws temporaries from the stream-ordered pool), so a chain of calls can be captured into a
+ * hipGraph on that stream and replayed. */
 ec_status ec_prepare_stream(ec_stream stream);
 ec_status ec_stream_destroy(ec_stream s);
 ec_status ec_stream_sync(ec_stream s);
@@ -159,7 +160,9 @@ ec_status ec_fill(ec_dtype t, void *dst, size_t n, const ec_value *value, ec_str
  * term is z alone (`(x o1 y) o2 z`, e.g. `(a + b) * c`) and dt[3]/p[3] are ignored.  Operands may alias.
  * An operand with p[k] == NULL is the scalar `scalars[k]` (the RHS-scalar form of src/buffer.rs:346-352,
  * e.g. `(buf + ones) * 2.0`, examples/masked.rs:12); at least one operand must be a buffer; `n` is the
- * shortest buffer operand's length. */
+ * shortest buffer operand's length.  Buffer operands of one cell type run as a single pass with no
+ * allocation; operands of mixed cell types are first widened to their CellType::union (the reference's
+ * `unify`, src/value.rs:103-107) into temporaries from the stream-ordered pool, freed in stream order. */
 #define EC_OP_NONE (-1)
 ec_status ec_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void *const p[4],
                    const ec_value *scalars_or_null, size_t n, double *out, ec_stream stream);
