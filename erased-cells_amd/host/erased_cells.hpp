@@ -34,6 +34,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -318,6 +319,34 @@ public:
         if (idx >= n_) throw std::out_of_range("index out of bounds");
         check(ec_upload(static_cast<char*>(ptr()) + idx * size_of(ct_), &c.raw().v, size_of(ct_), current_stream()));
     }
+    // impl Extend<C> for CellBuffer (buffer.rs:205-221): every item through num-traits' range-checked
+    // `to_<p>()` (value-based, unlike convert); a value that does not fit panics in the reference.
+    template <typename C> void extend(const std::vector<C>& items) {
+        const size_t sz = size_of(ct_), m = items.size();
+        std::vector<unsigned char> bytes(m * sz);
+        for (size_t i = 0; i < m; ++i) {
+            const double f = static_cast<double>(items[i]);
+            switch (ct_) {
+#define EC_EXT(ID, P)                                                                                         \
+    case CellType::ID: {                                                                                      \
+        if (std::is_integral<P>::value) {                                                                     \
+            const double lo = static_cast<double>(std::numeric_limits<P>::lowest()) - 1.0;                    \
+            const double hi = static_cast<double>(std::numeric_limits<P>::max()) + 1.0;                       \
+            if (f != f || !(f > lo && f < hi)) throw std::overflow_error("called `Option::unwrap()` on a `None` value"); \
+        }                                                                                                     \
+        const P v = static_cast<P>(items[i]);                                                                 \
+        std::memcpy(bytes.data() + i * sz, &v, sz);                                                           \
+        break;                                                                                                \
+    }
+                EC_HOST_WITH_CT(EC_EXT)
+#undef EC_EXT
+            }
+        }
+        CellBuffer grown(ct_, n_ + m);
+        if (n_) check(ec_copy(grown.ptr(), ptr(), n_ * sz, current_stream()));
+        if (m) check(ec_upload(static_cast<char*>(grown.ptr()) + n_ * sz, bytes.data(), bytes.size(), current_stream()));
+        *this = std::move(grown);
+    }
     CellBuffer convert(CellType cell_type) const {  // buffer.rs:150-167
         if (cell_type == ct_) return clone();
         if (!can_fit_into(ct_, cell_type)) throw NarrowingError(ct_, cell_type);
@@ -416,6 +445,13 @@ public:
     }
     size_t len() const { return n_; }
     bool is_empty() const { return n_ == 0; }
+    void extend(const std::vector<bool>& items) {  // impl Extend<bool> for Mask (mask.rs:83-87)
+        std::vector<uint8_t> b(items.begin(), items.end());
+        Mask grown(n_ + b.size());
+        if (n_) check(ec_copy(grown.ptr(), ptr(), n_, current_stream()));
+        if (!b.empty()) check(ec_upload(grown.ptr() + n_, b.data(), b.size(), current_stream()));
+        *this = std::move(grown);
+    }
     Mask clone() const {
         Mask m(n_);
         check(ec_copy(m.ptr(), ptr(), n_, current_stream()));
@@ -538,6 +574,13 @@ public:
     std::pair<CellValue, bool> get_with_mask(size_t i) const { return {buf_.get(i), mask_.get(i)}; }
     void put_with_mask(size_t i, const CellValue& v, bool m) { put(i, v); mask_.put(i, m); }  // :120-129
     std::pair<size_t, size_t> counts() const { return mask_.counts(); }                       // :132-134
+    template <typename C> void extend(const std::vector<std::pair<C, bool>>& items) {         // :280-287
+        std::vector<C> v;
+        std::vector<bool> m;
+        for (const auto& p : items) { v.push_back(p.first); m.push_back(p.second); }
+        buf_.extend(v);
+        mask_.extend(m);
+    }
     MaskedCellBuffer convert(CellType ct) const { return MaskedCellBuffer(buf_.convert(ct), mask_.clone()); }  // :200-206
     template <typename T> std::vector<T> to_vec() const { return buf_.to_vec<T>(); }
     template <typename T> std::vector<T> to_vec_with_nodata(NoData<T> no_data) const {  // :137-152

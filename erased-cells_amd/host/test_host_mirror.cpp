@@ -212,6 +212,13 @@ static void buffer_tests() {
         CHECK(wd(4, CellType::UInt8) < wd(4, CellType::Float32) && wd(4, CellType::Float32) > wd(4, CellType::UInt8));
         CHECK(wd(4, CellType::UInt8) < wd(5, CellType::UInt8) && wd(5, CellType::Float64) > wd(4, CellType::Float64));
     }
+    {  // extend (buffer.rs:489-498)
+        CellBuffer buf = CellBuffer::fill(3, CellValue(uint8_t(0)));
+        CHECK(!buf.is_empty() && buf.cell_type() == CellType::UInt8);
+        buf.extend(std::vector<int>{1});
+        CHECK(buf.cell_type() == CellType::UInt8 && buf.len() == 4 && buf.get(0) == CellValue(0) && buf.get(3) == CellValue(1));
+        CHECK_THROWS(std::overflow_error, buf.extend(std::vector<int>{300}));
+    }
     {  // shape rules: zip truncation, empty results are UInt8 (buffer.rs:327, :233-234)
         CellBuffer a = CellBuffer::with_defaults(5, CellType::Int16), b = CellBuffer::with_defaults(3, CellType::Float32);
         CHECK((a + b).len() == 3);
@@ -277,6 +284,11 @@ static void masked_tests() {
         CHECK(buf.get_masked(5) == CellValue(4));
         buf.put_with_mask(5, CellValue(uint8_t(99)), false);
         CHECK(!buf.get_masked(5).has_value());
+    }
+    {  // extend (masked_buffer.rs:449-455)
+        MaskedCellBuffer buf = MaskedCellBuffer::fill(3, CellValue(0));
+        buf.extend(std::vector<std::pair<int, bool>>{{1, false}});
+        CHECK(buf.get_masked(0) == CellValue(0) && !buf.get_masked(3).has_value() && buf.len() == 4);
     }
     {  // convert
         MaskedCellBuffer buf = MaskedCellBuffer::fill_with_mask_via<uint8_t>(4, filler_masker);

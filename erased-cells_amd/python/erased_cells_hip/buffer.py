@@ -276,6 +276,29 @@ class CellBuffer:
     def to_numpy(self) -> np.ndarray:
         return _download(self.mem, NP_DTYPES[self.ct], self.n)
 
+    def extend(self, values) -> None:
+        """impl Extend<C> for CellBuffer (src/buffer.rs:205-221): each item goes through num-traits'
+        range-checked `to_<p>()` (value-based, unlike `convert`) and panics when it does not fit."""
+        items = [_scalar(v) for v in values]
+        dt = NP_DTYPES[self.ct]
+        new = np.empty(len(items), dtype=dt)
+        for i, v in enumerate(items):
+            x = v.value
+            if dt.kind in "ui":
+                info = np.iinfo(dt)
+                f = float(x)
+                if f != f or not (info.min - 1 < f < info.max + 1):
+                    raise OverflowError(f"called `Option::unwrap()` on a `None` value: {v!r} does not fit {CT_NAMES[self.ct]}")
+                new[i] = int(x)  # truncation toward zero for float sources
+            else:
+                new[i] = dt.type(x)
+        grown = DeviceMem((self.n + new.size) * dt.itemsize)
+        if self.n:
+            check(lib().ec_copy(grown.ptr, self.mem.ptr, self.n * dt.itemsize, _stream))
+        if new.size:
+            check(lib().ec_upload(grown.window(self.n * dt.itemsize, new.nbytes).ptr, new.ctypes.data_as(C.c_void_p), new.nbytes, _stream))
+        self.mem, self.n = grown, self.n + new.size
+
     def clone(self) -> "CellBuffer":
         out = CellBuffer.empty(self.n, self.ct)
         check(lib().ec_copy(out.mem.ptr, self.mem.ptr, self.mem.nbytes, _stream))
@@ -439,6 +462,15 @@ class Mask:
         a = np.array([1 if value else 0], dtype=np.uint8)
         check(lib().ec_upload(self.mem.window(index, 1).ptr, a.ctypes.data_as(C.c_void_p), 1, _stream))
 
+    def extend(self, values) -> None:  # impl Extend<bool> for Mask (mask.rs:83-87)
+        new = np.asarray([bool(v) for v in values], dtype=np.uint8)
+        grown = DeviceMem(self.n + new.size)
+        if self.n:
+            check(lib().ec_copy(grown.ptr, self.mem.ptr, self.n, _stream))
+        if new.size:
+            check(lib().ec_upload(grown.window(self.n, new.size).ptr, new.ctypes.data_as(C.c_void_p), new.size, _stream))
+        self.mem, self.n = grown, self.n + new.size
+
     def clone(self) -> "Mask":
         out = Mask.empty(self.n)
         check(lib().ec_copy(out.mem.ptr, self.mem.ptr, self.n, _stream))
@@ -572,6 +604,11 @@ class MaskedCellBuffer:
 
     def counts(self) -> tuple[int, int]:
         return self._mask.counts()
+
+    def extend(self, pairs) -> None:  # impl Extend<(C, bool)> for MaskedCellBuffer (masked_buffer.rs:280-287)
+        pairs = list(pairs)
+        self._buf.extend([p[0] for p in pairs])
+        self._mask.extend([p[1] for p in pairs])
 
     def convert(self, ct: int) -> "MaskedCellBuffer":
         return MaskedCellBuffer(self._buf.convert(ct), self._mask.clone())

@@ -61,6 +61,23 @@ def test_buffer_defaults_put_get(ec):
         ec.CellBuffer.with_defaults(3, ec.UInt8).get(3)
 
 
+def test_buffer_and_masked_extend(ec):
+    """src/buffer.rs:489-498 (extend) and src/masked/masked_buffer.rs:449-455"""
+    buf = ec.CellBuffer.fill(3, ec.CellValue(ec.UInt8, 0))
+    assert not buf.is_empty() and buf.cell_type() == ec.UInt8
+    buf.extend([1])
+    assert buf.cell_type() == ec.UInt8 and buf.len() == 4
+    assert buf.get(0) == ec.CellValue.new(0) and buf.get(3) == ec.CellValue.new(1)
+    with pytest.raises(OverflowError):
+        buf.extend([300])  # to_u8() is None -> unwrap panics in the reference
+    m = ec.MaskedCellBuffer.fill(3, ec.CellValue.new(0))
+    m.extend([(1, False)])
+    assert m.get_masked(0) == ec.CellValue.new(0) and m.get_masked(3) is None and m.len() == 4
+    e = ec.CellBuffer.empty(0, ec.Float32)
+    e.extend([1.5, 2])
+    assert e.to_numpy().tolist() == [1.5, 2.0] and e.cell_type() == ec.Float32
+
+
 def test_buffer_to_vec(ec):
     """src/buffer.rs:501-513"""
     for ct in ec.CELL_TYPES:
