@@ -160,7 +160,7 @@ static ec_status launch_min_max(const void* p, const uint8_t* mask, size_t n, in
     const T* tp = static_cast<const T*>(p);
     unsigned grid = 0;
     if (n > 0) {
-        const bool al = aligned16(p, p, p) && (!mask || (reinterpret_cast<uintptr_t>(mask) % (16 / sizeof(T))) == 0);
+        const bool al = aligned16(p, p, p) && (!mask || aligned_to(mask, 16 / sizeof(T)));
         int cap = g_cus * g_tuning.reduce_bpc;
         if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
         if (al) {
@@ -447,6 +447,7 @@ extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     if (!std::strcmp(key, "binop_variant")) g_tuning.binop_variant = static_cast<int>(value);
     else if (!std::strcmp(key, "reduce_bpc")) g_tuning.reduce_bpc = value > 0 ? static_cast<int>(value) : 8;
     else if (!std::strcmp(key, "map_u")) g_tuning.map_u = static_cast<int>(value);
+    else if (!std::strcmp(key, "unaligned_vector")) g_tuning.unaligned_vector = value != 0;
     else return set_error(EC_ERR_ARG, "ec_tune_set: unknown key '%s'", key);
     return EC_OK;
 }
@@ -662,7 +663,7 @@ template <typename W>
 static ec_status mask_from_nd_w(const void* p, size_t n, const ec_value* nd, uint8_t* mask, hipStream_t s) {
     W w; std::memcpy(&w, &nd->v, sizeof w);
     MaskFromNodataFn<W> fn{static_cast<const W*>(p), mask, w};
-    const bool al = aligned16(p, p, p) && (reinterpret_cast<uintptr_t>(mask) % (16 / sizeof(W))) == 0;
+    const bool al = aligned16(p, p, p) && aligned_to(mask, 16 / sizeof(W));
     return launch_map(fn, n, al, s, "mask_from_nodata");
 }
 
@@ -687,7 +688,7 @@ template <typename W>
 static ec_status mask_select_w(const void* p, const uint8_t* mask, size_t n, const ec_value* nd, void* out, hipStream_t s) {
     W w; std::memcpy(&w, &nd->v, sizeof w);
     MaskSelectFn<W> fn{static_cast<const W*>(p), mask, static_cast<W*>(out), w};
-    const bool al = aligned16(p, out, out) && (reinterpret_cast<uintptr_t>(mask) % (16 / sizeof(W))) == 0;
+    const bool al = aligned16(p, out, out) && aligned_to(mask, 16 / sizeof(W));
     return launch_map(fn, n, al, s, "mask_select");
 }
 
@@ -740,7 +741,7 @@ extern "C" ec_status ec_mask_counts_device(const uint8_t* m, size_t n, uint64_t*
     if (n > 0) {
         int cap = g_cus * g_tuning.reduce_bpc;
         if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
-        const bool al = (reinterpret_cast<uintptr_t>(m) & 15u) == 0;
+        const bool al = aligned_to(m, 16);
         size_t tiles = al ? (n / 16 + size_t(kBlock) * kReduceU - 1) / (size_t(kBlock) * kReduceU) : (n + kBlock - 1) / kBlock;
         if (tiles < 1) tiles = 1;
         grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));

@@ -32,14 +32,14 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 
 template <bool NT, typename V>
 __device__ __forceinline__ void store_vec(V* p, V v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
+    if constexpr (NT) nt_store(v, p);
+    else plain_store(v, p);
 }
 
 template <bool NT, typename V>
 __device__ __forceinline__ V load_vec(const V* p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
+    if constexpr (NT) return nt_load(p);
+    else return plain_load(p);
 }
 
 // Workgroup -> tile map: even workgroups walk the buffer from the front, odd ones from the back, so
@@ -277,7 +277,7 @@ __device__ __forceinline__ void mask_and_body(const uint8_t* __restrict__ lm, co
     u32x4* __restrict__ o = reinterpret_cast<u32x4*>(om);
     const size_t stride = size_t(gridDim.x) * kBlock;
     for (size_t g = size_t(blockIdx.x) * kBlock + threadIdx.x; g < ngroups; g += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(a + g) & __builtin_nontemporal_load(b + g), o + g);
+        nt_store(nt_load(a + g) & nt_load(b + g), o + g);
     if (blockIdx.x == 0)
         for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) om[i] = lm[i] & rm[i];
 }

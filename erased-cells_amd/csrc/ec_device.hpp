@@ -115,4 +115,30 @@ __device__ __host__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
+// Global loads/stores of cell vectors.  The pointee type is declared with alignment 1: gfx950 runs with
+// unaligned global access enabled (the compiler therefore still emits ONE dword/dwordx2/dwordx4
+// instruction), so the same vector kernel serves any cell offset — a row-block of a raster whose width
+// is not a multiple of 16 cells, a window into a larger buffer — instead of dropping to cell-wise code.
+template <typename V>
+struct under_aligned {
+    typedef V type __attribute__((aligned(1)));
+};
+template <typename V>
+__device__ __forceinline__ V nt_load(const V* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const typename under_aligned<V>::type*>(p));
+}
+template <typename V>
+__device__ __forceinline__ void nt_store(V v, V* p) {
+    __builtin_nontemporal_store(v, reinterpret_cast<typename under_aligned<V>::type*>(p));
+}
+template <typename V>
+__device__ __forceinline__ V plain_load(const V* p) {
+    return *reinterpret_cast<const typename under_aligned<V>::type*>(p);
+}
+template <typename V>
+__device__ __forceinline__ void plain_store(V v, V* p) {
+    *reinterpret_cast<typename under_aligned<V>::type*>(p) = v;
+}
+
+
 }  // namespace ecd

@@ -24,7 +24,7 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
     fa.o1 = static_cast<int8_t>(o1);
     fa.o2 = static_cast<int8_t>(o2);
     fa.o3 = static_cast<int8_t>(o3);
-    bool aligned = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    bool aligned = aligned_to(out, 16);
     int first_buf = -1;
     for (int k = 0; k < 4; ++k) {
         const int src = k < nops ? k : 2;  // unused w mirrors z
@@ -42,13 +42,13 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         fa.dt[k] = static_cast<int8_t>(dt[src]);
         for (int j = 0; j < k; ++j)
             if (!fa.is_sc[j] && fa.p[j] == fa.p[k] && fa.dt[j] == fa.dt[k]) { fa.alias[k] = static_cast<int8_t>(j); break; }
-        aligned = aligned && (reinterpret_cast<uintptr_t>(fa.p[k]) & 15u) == 0;
+        aligned = aligned && aligned_to(fa.p[k], 16);
     }
     if (first_buf < 0) return set_error(EC_ERR_ARG, "ec_fused: at least one operand must be a buffer");
     fa.nmask = 0;
     if (masks) {
         if (!out_mask) return set_error(EC_ERR_ARG, "ec_masked_fused: null out_mask");
-        aligned = aligned && (reinterpret_cast<uintptr_t>(out_mask) & 15u) == 0;
+        aligned = aligned && aligned_to(out_mask, 16);
         for (int k = 0; k < nops; ++k) {
             if (fa.is_sc[k]) continue;  // a scalar carries no mask (masked_buffer.rs:353-364)
             if (!masks[k]) return set_error(EC_ERR_ARG, "ec_masked_fused: null mask %d", k);
@@ -56,7 +56,7 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
             for (int j = 0; j < fa.nmask; ++j) seen = seen || fa.m[j] == masks[k];
             if (!seen) {
                 fa.m[fa.nmask++] = masks[k];
-                aligned = aligned && (reinterpret_cast<uintptr_t>(masks[k]) & 15u) == 0;
+                aligned = aligned && aligned_to(masks[k], 16);
             }
         }
     }

@@ -69,8 +69,8 @@ __device__ __forceinline__ double fused_cell(const FusedArgs& fa, double x, doub
 }
 
 // compile-time ops: a wave-uniform `switch` per cell costs ≈30 % on the NDVI kernel (it serialises the
-// four cells of a lane; tools/tune_fused.hip: 422 vs 546 Gcells/s), so the vector kernels are
-// instantiated per op triple (4 x 4 x 5 = 80) and only the operand TYPES stay run-time in k_fused.
+// four cells of a lane; tools/tune_fused.hip: 422 vs 546 Gcells/s), so the vector kernel is
+// instantiated per op triple (4 x 4 x 5 = 80) and per cell type.
 template <int O1, int O2, int O3>
 __device__ __forceinline__ double fused_cell_t(double x, double y, double z, double w) {
     const double t1 = cell_op<O1, true>(x, y);
@@ -89,9 +89,9 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
         const size_t stride = size_t(gridDim.x) * kBlock;
         u32x4* __restrict__ om = reinterpret_cast<u32x4*>(out_mask);
         for (size_t g = size_t(blockIdx.x) * kBlock + threadIdx.x; g < ngroups; g += stride) {
-            u32x4 acc = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa.m[0]) + g);
-            for (int k = 1; k < fa.nmask; ++k) acc &= __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fa.m[k]) + g);
-            __builtin_nontemporal_store(acc, om + g);
+            u32x4 acc = nt_load(reinterpret_cast<const u32x4*>(fa.m[0]) + g);
+            for (int k = 1; k < fa.nmask; ++k) acc &= nt_load(reinterpret_cast<const u32x4*>(fa.m[k]) + g);
+            nt_store(acc, om + g);
         }
         if (blockIdx.x == 0)
             for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) {
@@ -127,10 +127,10 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
     for (int j = 0; j < kFusedU; ++j) {
         const size_t pr = base + size_t(j) * kBlock;
         if (full || pr < npairs) {
-            if (ld_x) x[j] = __builtin_nontemporal_load(px + pr);
-            if (ld_y) y[j] = __builtin_nontemporal_load(py + pr);
-            if (ld_z) z[j] = __builtin_nontemporal_load(pz + pr);
-            if (ld_w) w[j] = __builtin_nontemporal_load(pw + pr);
+            if (ld_x) x[j] = nt_load(px + pr);
+            if (ld_y) y[j] = nt_load(py + pr);
+            if (ld_z) z[j] = nt_load(pz + pr);
+            if (ld_w) w[j] = nt_load(pw + pr);
         }
     }
 #pragma unroll
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
             D2 o;
             o.x = fused_cell_t<O1, O2, O3>(vx.x, vy.x, vz.x, vw.x);
             o.y = fused_cell_t<O1, O2, O3>(vx.y, vy.y, vz.y, vw.y);
-            __builtin_nontemporal_store(o, op + pr);
+            nt_store(o, op + pr);
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {

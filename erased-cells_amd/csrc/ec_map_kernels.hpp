@@ -66,9 +66,9 @@ struct ConvertFn {
     using In = SV;
     const S* __restrict__ src;
     D* __restrict__ dst;
-    __device__ __forceinline__ In load(size_t g) const { return __builtin_nontemporal_load(reinterpret_cast<const SV*>(src) + g); }
+    __device__ __forceinline__ In load(size_t g) const { return nt_load(reinterpret_cast<const SV*>(src) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
-        __builtin_nontemporal_store(__builtin_convertvector(x, DV), reinterpret_cast<DV*>(dst) + g);
+        nt_store(__builtin_convertvector(x, DV), reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = static_cast<D>(src[i]); }
 };
@@ -105,12 +105,12 @@ struct NegFn {
     using In = SV;
     const T* __restrict__ src;
     O* __restrict__ dst;
-    __device__ __forceinline__ In load(size_t g) const { return __builtin_nontemporal_load(reinterpret_cast<const SV*>(src) + g); }
+    __device__ __forceinline__ In load(size_t g) const { return nt_load(reinterpret_cast<const SV*>(src) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         DV o;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = neg_cell<T>(x[k]);
-        __builtin_nontemporal_store(o, reinterpret_cast<DV*>(dst) + g);
+        nt_store(o, reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = neg_cell<T>(src[i]); }
 };
@@ -128,7 +128,7 @@ struct FillFn {
         DV o;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = value;
-        __builtin_nontemporal_store(o, reinterpret_cast<DV*>(dst) + g);
+        nt_store(o, reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = value; }
 };
@@ -145,12 +145,12 @@ struct MaskFromNodataFn {
     const W* __restrict__ src;
     uint8_t* __restrict__ mask;
     W nd;
-    __device__ __forceinline__ In load(size_t g) const { return __builtin_nontemporal_load(reinterpret_cast<const SV*>(src) + g); }
+    __device__ __forceinline__ In load(size_t g) const { return nt_load(reinterpret_cast<const SV*>(src) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         MV m;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) m[k] = x[k] != nd;
-        __builtin_nontemporal_store(m, reinterpret_cast<MV*>(mask) + g);
+        nt_store(m, reinterpret_cast<MV*>(mask) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { mask[i] = src[i] != nd; }
 };
@@ -167,14 +167,14 @@ struct MaskSelectFn {
     W* __restrict__ dst;
     W nd;
     __device__ __forceinline__ In load(size_t g) const {
-        return In{__builtin_nontemporal_load(reinterpret_cast<const SV*>(src) + g),
-                  __builtin_nontemporal_load(reinterpret_cast<const MV*>(mask) + g)};
+        return In{nt_load(reinterpret_cast<const SV*>(src) + g),
+                  nt_load(reinterpret_cast<const MV*>(mask) + g)};
     }
     __device__ __forceinline__ void store(size_t g, const In& in) const {
         SV o;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = in.m[k] ? in.x[k] : nd;
-        __builtin_nontemporal_store(o, reinterpret_cast<SV*>(dst) + g);
+        nt_store(o, reinterpret_cast<SV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = mask[i] ? src[i] : nd; }
 };
@@ -188,11 +188,11 @@ struct MaskBin {
     const uint8_t* __restrict__ r;
     uint8_t* __restrict__ out;
     __device__ __forceinline__ In load(size_t g) const {
-        return In{__builtin_nontemporal_load(reinterpret_cast<const u32x4*>(l) + g),
-                  __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(r) + g)};
+        return In{nt_load(reinterpret_cast<const u32x4*>(l) + g),
+                  nt_load(reinterpret_cast<const u32x4*>(r) + g)};
     }
     __device__ __forceinline__ void store(size_t g, const In& in) const {
-        __builtin_nontemporal_store(KIND == 0 ? (in.a & in.b) : (in.a | in.b), reinterpret_cast<u32x4*>(out) + g);
+        nt_store(KIND == 0 ? (in.a & in.b) : (in.a | in.b), reinterpret_cast<u32x4*>(out) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { out[i] = KIND == 0 ? (l[i] & r[i]) : (l[i] | r[i]); }
 };
@@ -202,9 +202,9 @@ struct MaskNot {
     using In = u32x4;
     const uint8_t* __restrict__ m;
     uint8_t* __restrict__ out;
-    __device__ __forceinline__ In load(size_t g) const { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(m) + g); }
+    __device__ __forceinline__ In load(size_t g) const { return nt_load(reinterpret_cast<const u32x4*>(m) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
-        __builtin_nontemporal_store(x ^ 0x01010101u, reinterpret_cast<u32x4*>(out) + g);
+        nt_store(x ^ 0x01010101u, reinterpret_cast<u32x4*>(out) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { out[i] = m[i] ^ 1; }
 };
@@ -228,7 +228,7 @@ struct SynthFn {
         DV o;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = gen(g * CPL + k);
-        __builtin_nontemporal_store(o, reinterpret_cast<DV*>(dst) + g);
+        nt_store(o, reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = gen(i); }
 };
@@ -246,7 +246,7 @@ struct SynthMaskFn {
         DV o;
 #pragma unroll
         for (int k = 0; k < 16; ++k) o[k] = gen(g * 16 + k);
-        __builtin_nontemporal_store(o, reinterpret_cast<DV*>(dst) + g);
+        nt_store(o, reinterpret_cast<DV*>(dst) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { dst[i] = gen(i); }
 };

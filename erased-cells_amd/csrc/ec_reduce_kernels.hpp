@@ -170,8 +170,8 @@ __global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict
             MV m[U] = {};
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                x[j] = __builtin_nontemporal_load(pv + base + size_t(j) * kBlock);
-                if constexpr (MASKED) m[j] = __builtin_nontemporal_load(mv + base + size_t(j) * kBlock);
+                x[j] = nt_load(pv + base + size_t(j) * kBlock);
+                if constexpr (MASKED) m[j] = nt_load(mv + base + size_t(j) * kBlock);
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) fold(x[j], m[j]);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_first_diff_partials(const W* __restr
             for (int j = 0; j < U; ++j) {
                 const size_t g = base + size_t(j) * kBlock;
                 if (g < ngroups) {
-                    const WV a = __builtin_nontemporal_load(lv + g), b = __builtin_nontemporal_load(rv + g);
+                    const WV a = nt_load(lv + g), b = nt_load(rv + g);
 #pragma unroll
                     for (int k = CPL - 1; k >= 0; --k)
                         if (a[k] != b[k]) { const uint64_t i = g * CPL + k; first = i < first ? i : first; }
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void k_mask_count_partials(const uint8_t* _
             for (int j = 0; j < U; ++j) {
                 const size_t g = base + size_t(j) * kBlock;
                 if (g < ngroups) {
-                    u32x4 x = __builtin_nontemporal_load(mv + g);
+                    u32x4 x = nt_load(mv + g);
                     c32 += __builtin_popcount(x.x & 0x01010101u) + __builtin_popcount(x.y & 0x01010101u) +
                            __builtin_popcount(x.z & 0x01010101u) + __builtin_popcount(x.w & 0x01010101u);
                 }

@@ -18,13 +18,16 @@ constexpr bool kNtLoad = true;     // +6 % on the divide (tune_binop_v2.log: 627
 constexpr int kReduceU = 4;
 constexpr int kMaxReduceBlocks = 4096;
 
+struct Tuning;
+Tuning& tuning();
 struct Tuning {
     int binop_variant = 0;  // 0 = direct narrow loads, 1 = LDS-staged narrow operands
     int reduce_bpc = 8;     // blocks per CU for reductions (partials are per block)
     int map_u = 2;          // 16-B groups per lane per tile for the map kernels (1, 2 or 4)
+    int unaligned_vector = 1;  // 1 = vector kernels at any cell offset (gfx950 unaligned global access);
+                               // 0 = pointers that are not 16-byte aligned run the cell-wise kernels
 };
 
-Tuning& tuning();
 int device_cus();
 
 ec_status ensure_ready();  // EC_ERR_NOT_INITIALIZED unless ec_init ran; binds the calling thread to the device
@@ -33,8 +36,15 @@ ec_status set_narrowing(int src, int dst);
 ec_status check_launch(const char* what);
 ec_status check_hip(hipError_t e, const char* what);
 
+// May the vector kernels run on these pointers?  Their loads and stores are declared under-aligned
+// (ec_device.hpp nt_load/nt_store), so the answer is yes at any cell offset unless the
+// "unaligned_vector" knob is turned off.
 inline bool aligned16(const void* a, const void* b, const void* c) {
-    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15u) == 0;
+    return tuning().unaligned_vector ||
+           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15u) == 0;
+}
+inline bool aligned_to(const void* a, size_t bytes) {
+    return tuning().unaligned_vector || reinterpret_cast<uintptr_t>(a) % bytes == 0;
 }
 
 // Element-wise kernels: one workgroup per tile.

@@ -12,7 +12,8 @@
  *
  * Conventions
  *  - Every `const void*` / `void*` data argument is a DEVICE pointer (ec_alloc,
- *    hipMalloc or any other HIP allocation) unless the name says `host`.
+ *    hipMalloc or any other HIP allocation) unless the name says `host`.  It needs
+ *    only its cell type's natural alignment: windows at any cell offset are fine.
  *  - Inputs are never written.  Outputs are caller-allocated; the library keeps
  *    no hidden buffers except a small per-stream scratch for reduction partials.
  *  - All compute entry points are asynchronous on `stream` (a hipStream_t; NULL
@@ -237,7 +238,9 @@ ec_status ec_synth_fill(ec_dtype t, void *dst, size_t n, uint64_t seed, uint64_t
 /* mask[i] = splitmix64(seed ^ (base+i)) % 100 >= pct_nodata */
 ec_status ec_synth_mask(uint8_t *dst, size_t n, uint64_t seed, uint64_t base, uint32_t pct_nodata, ec_stream stream);
 /* Tuning knobs: "binop_variant" (0 direct narrow loads, 1 LDS-staged), "reduce_bpc" (workgroups per CU for reductions),
- * "map_u" (16-B groups per lane per tile of the map kernels: 1, 2 or 4). */
+ * "map_u" (16-B groups per lane per tile of the map kernels: 1, 2 or 4), "unaligned_vector" (1, default: vector
+ * kernels at any cell offset via unaligned global access; 0: pointers that are not 16-byte aligned run the
+ * one-cell-per-lane kernels). */
 ec_status ec_tune_set(const char *key, int64_t value);
 
 #ifdef __cplusplus

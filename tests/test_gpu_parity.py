@@ -25,6 +25,15 @@ def ec():
     return ec
 
 
+@pytest.fixture(params=[1, 0], ids=["vector-any-offset", "cellwise-when-unaligned"])
+def ua(ec, request):
+    """Windows that are not 16-byte aligned: vector kernels with unaligned global access (default) or,
+    with the knob off, the cell-wise kernels.  Both must match the oracle."""
+    ec.lib().ec_tune_set(b"unaligned_vector", request.param)
+    yield request.param
+    ec.lib().ec_tune_set(b"unaligned_vector", 1)
+
+
 def _both_nan(l, r):
     with np.errstate(all="ignore"):
         return np.isnan(l.astype(np.float64)) & np.isnan(r.astype(np.float64))
@@ -63,9 +72,9 @@ def test_binop_reference_shaped_oracle_and_variants(ec, variant):
 
 
 @pytest.mark.parametrize("variant", [0, 1])
-def test_binop_lengths_tails_and_alignment(ec, variant):
+def test_binop_lengths_tails_and_alignment(ec, ua, variant):
     """Ragged sizes around every tile boundary, zip truncation, and odd cell offsets
-    (row-block windows that are not 16-byte aligned take the cell-wise kernel)."""
+    (row-block windows that are not 16-byte aligned: fixture `ua`)."""
     ec.lib().ec_tune_set(b"binop_variant", variant)
     try:
         big = 2 * 1024 * 1024 + 5
@@ -136,7 +145,7 @@ def test_binop_scalar_bit_exact(ec, lct):
 
 # ---------------------------------------------------------------- neg: src/buffer.rs:360-365
 @pytest.mark.parametrize("ct", range(NT))
-def test_neg_bit_exact(ec, ct):
+def test_neg_bit_exact(ec, ua, ct):
     for n in (1, 15, 16, 17, 4099, 70001):
         a = rand_cells(ct, n, 41)
         got = -ec.CellBuffer.from_vec(a)
@@ -173,7 +182,7 @@ def test_convert_all_pairs(ec, sct):
 
 # ---------------------------------------------------------------- min_max: src/buffer.rs:169-173, masked_buffer.rs:208-217
 @pytest.mark.parametrize("ct", range(NT))
-def test_min_max_total_order(ec, ct):
+def test_min_max_total_order(ec, ua, ct):
     for n in (0, 1, 5, 255, 4096, 100003, 1 << 21):
         a = rand_cells(ct, n, 61)
         d = ec.CellBuffer.from_vec(a)
@@ -220,7 +229,7 @@ def test_float_nodata_is_bitwise(ec):
     assert m.tolist() == [1, 1, 1, 0, 1]
 
 
-def test_mask_logic_and_counts(ec):
+def test_mask_logic_and_counts(ec, ua):
     for n in (0, 1, 15, 16, 17, 4095, 4097, 1 << 20, (1 << 22) + 3):
         a, b = rand_mask(n, 81), rand_mask(n, 82, 0.4)
         da, db = ec.Mask.new(a), ec.Mask.new(b)
@@ -240,7 +249,7 @@ def test_mask_logic_and_counts(ec):
 
 # ---------------------------------------------------------------- masked binop: src/masked/masked_buffer.rs:326-335
 @pytest.mark.parametrize("variant", [0, 1])
-def test_masked_binop_fused(ec, variant):
+def test_masked_binop_fused(ec, ua, variant):
     ec.lib().ec_tune_set(b"binop_variant", variant)
     try:
         for lct, rct in [(eco.F32, eco.F32), (eco.U8, eco.U16), (eco.F64, eco.F32), (eco.I64, eco.U8)]:
@@ -255,7 +264,7 @@ def test_masked_binop_fused(ec, variant):
                     # masked-out cells are still computed (masked_buffer.rs:331)
                     assert_f64_bits_equal(got.buffer().to_numpy(), eco.f_binop(op, l, r), nan_by_class_where=loose)
                     assert np.array_equal(got.mask().to_numpy(), eco.mask_and(lm, rm))
-        # unaligned windows -> cell-wise kernel
+        # unaligned windows (fixture `ua`: vector kernel or cell-wise kernel)
         l, r = rand_cells(eco.F32, 3000, 95), rand_cells(eco.F32, 3000, 96)
         lm, rm = rand_mask(3000, 97), rand_mask(3000, 98)
         ml = ec.MaskedCellBuffer(ec.CellBuffer.from_vec(l), ec.Mask.new(lm)).shard(1, 2000)
@@ -270,7 +279,7 @@ def test_masked_binop_fused(ec, variant):
 
 # ---------------------------------------------------------------- Ord / Eq on the device: src/buffer.rs:373-436
 @pytest.mark.parametrize("ct", range(NT))
-def test_buffer_cmp_on_device(ec, ct):
+def test_buffer_cmp_on_device(ec, ua, ct):
     import ctypes as C
     n = 300007
     a = rand_cells(ct, n, 101)
@@ -301,7 +310,7 @@ def test_buffer_cmp_on_device(ec, ct):
 
 
 # ---------------------------------------------------------------- fused chains == eager chains
-def test_fused_expression_equals_eager_chain(ec):
+def test_fused_expression_equals_eager_chain(ec, ua):
     """(x o1 y) o2 (z o3 w) in one pass is bit-identical to the reference's eager operator chain."""
     rng = np.random.default_rng(77)
     for trial in range(40):
@@ -324,7 +333,7 @@ def test_fused_expression_equals_eager_chain(ec):
         e2 = eco.f_binop(o3, h[2], h[3]) if four else h[2]
         eo = eco.f_binop(o2, e1, e2)
         assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=np.isnan(eo))
-    # unaligned windows take the cell-wise kernel
+    # unaligned windows (fixture `ua`)
     a, b = rand_cells(eco.U16, 5000, 301), rand_cells(eco.U16, 5000, 302)
     da, db = ec.CellBuffer.from_vec(a).shard(1, 4000), ec.CellBuffer.from_vec(b).shard(3, 4000)
     got = ec.fused.ndvi(da, db)
@@ -367,7 +376,7 @@ def test_fused_masked_expression_equals_eager_chain(ec):
         assert got.counts() == exp.counts()
 
 
-def test_randomised_shapes_types_and_windows(ec):
+def test_randomised_shapes_types_and_windows(ec, ua):
     """Property test (hypothesis): any type pair, op, length and pair of window offsets gives the oracle's
     bits — exercises every vector/cell-wise path choice, tile boundary and ragged tail."""
     from hypothesis import given, settings, strategies as st, HealthCheck
