@@ -181,8 +181,8 @@ __global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict
                 const size_t g = base + size_t(j) * kBlock;
                 if (g < ngroups) {
                     MV m = {};
-                    if constexpr (MASKED) m = mv[g];
-                    fold(pv[g], m);
+                    if constexpr (MASKED) m = plain_load(mv + g);
+                    fold(plain_load(pv + g), m);
                 }
             }
         }
