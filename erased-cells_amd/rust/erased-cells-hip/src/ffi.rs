@@ -30,19 +30,29 @@ extern "C" {
     pub fn ec_shutdown() -> ec_status;
     pub fn ec_last_error_string() -> *const c_char;
     pub fn ec_last_narrowing(src: *mut ec_dtype, dst: *mut ec_dtype) -> ec_status;
+    pub fn ec_device_info(n_cu: *mut i32, hbm_bytes: *mut u64, name: *mut c_char, name_cap: usize) -> ec_status;
 
     pub fn ec_alloc(dptr: *mut *mut c_void, bytes: usize) -> ec_status;
     pub fn ec_free(dptr: *mut c_void) -> ec_status;
     pub fn ec_alloc_async(dptr: *mut *mut c_void, bytes: usize, s: ec_stream) -> ec_status;
     pub fn ec_free_async(dptr: *mut c_void, s: ec_stream) -> ec_status;
+    pub fn ec_stream_create(out: *mut ec_stream) -> ec_status;
     pub fn ec_prepare_stream(s: ec_stream) -> ec_status;
+    pub fn ec_stream_destroy(s: ec_stream) -> ec_status;
+    pub fn ec_stream_sync(s: ec_stream) -> ec_status;
     pub fn ec_upload(dst_dev: *mut c_void, src_host: *const c_void, bytes: usize, s: ec_stream) -> ec_status;
     pub fn ec_download(dst_host: *mut c_void, src_dev: *const c_void, bytes: usize, s: ec_stream) -> ec_status;
     pub fn ec_copy(dst_dev: *mut c_void, src_dev: *const c_void, bytes: usize, s: ec_stream) -> ec_status;
 
     pub fn ec_union(a: ec_dtype, b: ec_dtype) -> ec_dtype;
     pub fn ec_can_fit_into(src: ec_dtype, dst: ec_dtype) -> i32;
+    pub fn ec_size_of(t: ec_dtype) -> usize;
     pub fn ec_neg_result_type(t: ec_dtype) -> ec_dtype;
+    pub fn ec_min_value(t: ec_dtype, out: *mut ec_value) -> ec_status;
+    pub fn ec_max_value(t: ec_dtype, out: *mut ec_value) -> ec_status;
+    pub fn ec_nodata_default(t: ec_dtype, out: *mut ec_value) -> ec_status;
+    pub fn ec_value_convert(v: *const ec_value, dst: ec_dtype, out: *mut ec_value) -> ec_status;
+    pub fn ec_value_to_f64(v: *const ec_value) -> f64;
 
     pub fn ec_binop(op: ec_op, lt: ec_dtype, l: *const c_void, rt: ec_dtype, r: *const c_void, n: usize,
                     out: *mut f64, s: ec_stream) -> ec_status;
@@ -69,6 +79,9 @@ extern "C" {
     pub fn ec_mask_or(l: *const u8, r: *const u8, n: usize, out: *mut u8, s: ec_stream) -> ec_status;
     pub fn ec_mask_not(m: *const u8, n: usize, out: *mut u8, s: ec_stream) -> ec_status;
     pub fn ec_mask_counts(m: *const u8, n: usize, n_true: *mut u64, n_false: *mut u64, s: ec_stream) -> ec_status;
+    pub fn ec_mask_counts_device(m: *const u8, n: usize, counts2_dev: *mut u64, s: ec_stream) -> ec_status;
+    pub fn ec_first_difference(t: ec_dtype, l: *const c_void, r: *const c_void, n: usize, index: *mut u64,
+                               s: ec_stream) -> ec_status;
     pub fn ec_buffer_cmp(lt: ec_dtype, l: *const c_void, nl: usize, rt: ec_dtype, r: *const c_void, nr: usize,
                          ordering: *mut i32, s: ec_stream) -> ec_status;
     pub fn ec_fused(o1: ec_op, o2: ec_op, o3: ec_op, dt: *const ec_dtype, p: *const *const c_void,
@@ -80,4 +93,10 @@ extern "C" {
     pub fn ec_allreduce_counts(rccl_comm: *mut c_void, counts2_dev: *mut u64, s: ec_stream) -> ec_status;
     pub fn ec_shard_range(n_rows: u64, n_cols: u64, shard: u32, n_shards: u32, cell_offset: *mut u64,
                           cell_len: *mut u64) -> ec_status;
+
+    // test support: deterministic device-side inputs and tuning knobs
+    pub fn ec_synth_fill(t: ec_dtype, dst: *mut c_void, n: usize, seed: u64, base: u64, lo: f64, hi: f64,
+                         s: ec_stream) -> ec_status;
+    pub fn ec_synth_mask(dst: *mut u8, n: usize, seed: u64, base: u64, pct_nodata: u32, s: ec_stream) -> ec_status;
+    pub fn ec_tune_set(key: *const c_char, value: i64) -> ec_status;
 }

@@ -153,3 +153,21 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"ec_oracle|libec_oracle|from oracle|import oracle|\beco\.", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_rust_extern_block_declares_every_entry_point():
+    """The Rust binding (erased-cells_amd/rust/erased-cells-hip/src/ffi.rs) cannot be compiled in this image
+    (no Rust toolchain), so its `extern "C"` block is at least kept in lockstep with the header: same set of
+    symbols, same number of arguments each."""
+    import re
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "erased_cells.h")).read(), flags=re.S)
+    c_decls = {m.group(1): m.group(2) for m in re.finditer(r"\b(ec_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)}
+    rs = re.sub(r"//.*", "", open(os.path.join(ROOT, "erased-cells_amd", "rust", "erased-cells-hip", "src", "ffi.rs")).read())
+    r_decls = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (ec_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->[^;]*)?;", rs, flags=re.S)}
+
+    def argc(a):
+        a = a.strip()
+        return 0 if a in ("", "void") else len([x for x in a.split(",") if x.strip()])
+
+    assert set(c_decls) == set(r_decls), (sorted(set(c_decls) - set(r_decls)), sorted(set(r_decls) - set(c_decls)))
+    assert {k: argc(v) for k, v in c_decls.items()} == {k: argc(v) for k, v in r_decls.items()}
