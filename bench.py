@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true",
                     help="also time from_vec (H2D) + divide + to_vec (D2H) once; reported beside, never as `value`")
+    ap.add_argument("--no-reference-streams", action="store_true",
+                    help="skip the untimed reference streams (roofline.reference_streams) measured after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -319,6 +321,32 @@ def main():
             res["end_to_end_pcie"] = {"value": n / dt / 1e9, "unit": "Gcells/s", "seconds": dt,
                                       "what": "from_vec(u8)+from_vec(u16) over PCIe, divide, to_vec(f64) back; pageable host memory"}
             del r
+        if world == 1 and not args.no_reference_streams and args.workload == "div_u8_u16":
+            # SURVEY §8(d) "empirical ceiling": what plain streams of the same buffers reach on this box, so the
+            # fraction of *achievable* bandwidth can be read next to the fraction of the nominal 8 TB/s.  Outside
+            # the timed region; same launch shape family, no divide.
+            def rate(fn, nbytes, reps=60):
+                for _ in range(reps // 2):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return nbytes / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+
+            zero = ec.CellValue.new(0.0).to_ec()
+            keys = torch.empty(2, dtype=torch.int64, device="cuda")
+            res["roofline"]["reference_streams"] = {
+                "same_mix_add_u8_u16_GBps": rate(lambda: chk(L.ec_binop(ec.ADD, ec.UInt8, a.mem.ptr, ec.UInt16, b.mem.ptr, n,
+                                                                        out.mem.ptr, stream)), 11 * n),
+                "write_only_fill_f64_GBps": rate(lambda: chk(L.ec_fill(ec.Float64, out.mem.ptr, n, C.byref(zero), stream)), 8 * n),
+                "read_only_min_max_f64_GBps": rate(lambda: chk(L.ec_min_max_keys(ec.Float64, out.mem.ptr, None, n, keys.data_ptr(),
+                                                                                 stream)), 8 * n),
+                "what": "library kernels on the same buffers, untimed by `value`: 3 B read + 8 B written with an add instead "
+                        "of the divide; 8 B/cell written; 8 B/cell read",
+            }
         if world == 1 and not args.no_cpu_baseline and args.workload == "div_u8_u16":
             res["cpu_baseline"] = cpu_baseline(side, args.cpu_seconds)
         print(json.dumps(res), flush=True)

@@ -3,8 +3,9 @@
 `_ffi`     ctypes binding of include/erased_cells.h (fails loudly if the .so is missing)
 `buffer`   host mirror of CellBuffer / MaskedCellBuffer / Mask / NoData / CellValue
 `sharded`  row-block sharding across ranks + the RCCL all-reduce for min/max and counts
+`wire`     serde/JSON shape of the core types (interop only; parity unpinned)
 """
-from . import _ffi, fused, raster
+from . import _ffi, fused, raster, wire
 from ._ffi import EcError, NarrowingError, build, lib
 from .buffer import (ADD, CELL_TYPES, CT_NAMES, DIV, MUL, NP_DTYPES, SUB, CellBuffer, CellValue, DeviceMem,
                      Float32, Float64, Int8, Int16, Int32, Int64, Mask, MaskedCellBuffer, NoData, UInt8,

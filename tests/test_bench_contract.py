@@ -41,5 +41,7 @@ def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert abs(rf["achieved"] - 11 * rf["cells_per_launch"] / (rf["launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
     assert 0.05 < rf["frac"] < 1.0
+    rs = rf["reference_streams"]  # untimed plain streams of the same buffers (SURVEY §8d "empirical ceiling")
+    assert all(0 < rs[k] < 8000.0 for k in ("same_mix_add_u8_u16_GBps", "write_only_fill_f64_GBps", "read_only_min_max_f64_GBps"))
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Gcells/s" and cb["value"] > 0 and cb["sample"]

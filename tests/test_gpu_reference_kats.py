@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from tiff_util import read_tiff
+from vectors import bits_of, rand_cells
 
 pytestmark = pytest.mark.gpu
 
@@ -76,6 +77,37 @@ def test_buffer_and_masked_extend(ec):
     e = ec.CellBuffer.empty(0, ec.Float32)
     e.extend([1.5, 2])
     assert e.to_numpy().tolist() == [1.5, 2.0] and e.cell_type() == ec.Float32
+
+
+def test_serde_wire_shapes_round_trip(ec):
+    """serde's externally tagged shapes (parity unpinned — the reference holds no serialized
+    fixture; see erased_cells_hip/wire.py)."""
+    w = ec.wire
+    assert w.dumps(ec.CellBuffer.from_vec(np.array([1, 2, 3], np.uint8))) == '{"UInt8":[1,2,3]}'
+    assert w.dumps(ec.CellBuffer.from_vec(np.array([1.5, -2.0], np.float32))) == '{"Float32":[1.5,-2.0]}'
+    assert w.dumps(ec.Mask.new([True, False])) == "[true,false]"
+    m = ec.MaskedCellBuffer.from_vec_with_nodata(np.array([0, 7, 0, 9], np.uint16), ec.NoData.new(0))
+    assert w.dumps(m) == '[{"UInt16":[0,7,0,9]},[false,true,false,true]]'
+    assert w.dumps(ec.CellValue.new(np.int64(-5))) == '{"Int64":-5}'
+    assert [w.to_wire(x) for x in (ec.NoData.none(), ec.NoData.default(), ec.NoData.new(3))] == ["None", "Default", {"Value": 3}]
+    assert w.cell_type_to_wire(ec.Float64) == "Float64" and w.cell_type_from_wire("Int8") == ec.Int8
+    for ct in ec.CELL_TYPES:
+        a = rand_cells(ct, 257, 900 + ct)
+        if ec.NP_DTYPES[ct].kind == "f":
+            a = np.where(np.isfinite(a), a, 1.0).astype(a.dtype)  # non-finite cells serialize as null
+        b = w.loads_buffer(w.dumps(ec.CellBuffer.from_vec(a)))
+        assert b.cell_type() == ct and np.array_equal(bits_of(b.to_numpy()), bits_of(a))
+    back = w.loads_masked(w.dumps(m))
+    assert back.buffer() == m.buffer() and back.mask() == m.mask()
+    assert w.to_wire(ec.CellBuffer.from_vec(np.array([np.nan, np.inf, 1.0])))["Float64"] == [None, None, 1.0]
+    for bad in ('{"UInt8":[256]}', '{"UInt8":[1.5]}', '{"Float64":[null]}', '{"UInt57":[1]}', '{"UInt8":[1],"Int8":[1]}'):
+        with pytest.raises(ValueError):
+            w.loads_buffer(bad)
+    with pytest.raises(ValueError):
+        w.loads_masked('[{"UInt8":[1]}]')
+    with pytest.raises(AssertionError):
+        w.loads_masked('[{"UInt8":[1,2]},[true]]')  # MaskedCellBuffer::new length assert (masked_buffer.rs:48-53)
+    assert w.loads_buffer('{"Int32":[]}').cell_type() == ec.Int32
 
 
 def test_buffer_to_vec(ec):
