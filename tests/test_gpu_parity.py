@@ -386,12 +386,12 @@ def test_randomised_shapes_types_and_windows(ec, ua):
     mpool = rand_mask(70000, 950)
     dmask = ec.Mask.new(mpool)
 
-    @settings(max_examples=200, deadline=None, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
     @given(lt=st.integers(0, NT - 1), rt=st.integers(0, NT - 1), op=st.integers(0, 3),
            n=st.one_of(st.integers(0, 40), st.integers(500, 1100), st.integers(4000, 4200), st.integers(60000, 65000)),
            lo=st.sampled_from([0, 1, 2, 3, 5, 8, 16, 17, 32, 48, 64, 1000]),
            ro=st.sampled_from([0, 1, 4, 7, 16, 31, 32, 64, 999]),
-           variant=st.integers(0, 1), kind=st.integers(0, 4))
+           variant=st.integers(0, 1), kind=st.integers(0, 8))
     def run(lt, rt, op, n, lo, ro, variant, kind):
         l, r = pool[lt][lo:lo + n], pool[rt][ro:ro + n]
         dl, dr = dev[lt].shard(lo, n), dev[rt].shard(ro, n)
@@ -425,10 +425,41 @@ def test_randomised_shapes_types_and_windows(ec, ua):
             else:
                 with pytest.raises(ec.NarrowingError):
                     dl.convert(rt)
-        else:              # compare + mask from nodata
+        elif kind == 4:    # compare + mask from nodata
             assert dl.cmp(dr) == eco.buffer_cmp(l, r)
             nd = eco.nodata_value(eco.ND_DEFAULT, lt)
             assert np.array_equal(ec.mask_from_nodata(dl, ec.NoData.default()).to_numpy(), eco.f_mask_from_nodata(l, nd))
+        elif kind == 5:    # buffer op scalar (the scalar: a finite cell of the other pool)
+            sval = pool[rt][ro + 70000 - 1000]
+            with np.errstate(all="ignore"):
+                if np.isnan(np.float64(sval)):
+                    sval = pool[rt].dtype.type(3)
+            got = dl._binop(op, ec.CellValue(rt, sval))
+            if n == 0:
+                assert got.cell_type() == ec.UInt8 and got.len() == 0
+            else:
+                assert_f64_bits_equal(got.to_numpy(), eco.f_binop_scalar(op, l, eco.Value.of(rt, sval)))
+        elif kind == 6:    # mask logic, counts and select on windows
+            ma, mb = dmask.shard(lo, n), dmask.shard(ro, n)
+            ha, hb = mpool[lo:lo + n], mpool[ro:ro + n]
+            assert np.array_equal((ma & mb).to_numpy(), eco.mask_and(ha, hb))
+            assert np.array_equal((ma | mb).to_numpy(), eco.mask_or(ha, hb))
+            assert np.array_equal((~ma).to_numpy(), eco.mask_not(ha))
+            assert ma.counts() == eco.mask_counts(ha)
+            nd = eco.nodata_value(eco.ND_DEFAULT, lt)
+            got = ec.MaskedCellBuffer(dl, mb).to_vec_with_nodata(lt, ec.NoData.default())
+            assert np.array_equal(bits_of(got), bits_of(eco.f_mask_select(l, hb, nd)))
+        else:              # fused chains on windows == the eager chain (kind 7: four operands, kind 8: scalar third)
+            o2, o3 = (op + 1) % 4, (op + 2) % 4
+            if kind == 7:
+                got = ec.fused.expr(dl, op, dr, o2, dr, o3, dl)
+                exp = (dl._binop(op, dr))._binop(o2, dr._binop(o3, dl))
+            else:
+                got = ec.fused.expr(dl, op, dr, o2, 2.5)
+                exp = (dl._binop(op, dr))._binop(o2, 2.5)
+            assert got.cell_type() == exp.cell_type() and got.len() == exp.len()
+            if n:
+                assert np.array_equal(bits_of(got.to_numpy()), bits_of(exp.to_numpy()))
 
     try:
         run()
