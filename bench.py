@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true",
                     help="also time from_vec (H2D) + divide + to_vec (D2H) once; reported beside, never as `value`")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the K timed steps into one hipGraph and replay it (every launch still executes); "
+                         "removes the host's per-launch cost from short steps such as a 1/8 shard's ≈55 µs divide")
     ap.add_argument("--no-reference-streams", action="store_true",
                     help="skip the untimed reference streams (roofline.reference_streams) measured after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
@@ -270,12 +273,32 @@ def main():
         ramp += 20
     for _ in range(args.warmup):
         step()
+    graph = None
+    if args.graph and args.workload == "minmax" and use_dist:
+        sys.exit("--graph does not capture the all-reduce of the sharded minmax workload")
+    if args.graph:
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        ec.set_stream(cap.cuda_stream)
+        stream = cap.cuda_stream  # `step` closures read this name at call time
+        chk(L.ec_prepare_stream(stream))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=cap):
+            for _ in range(args.steps):
+                step()
+        stream = torch.cuda.current_stream().cuda_stream
+        ec.set_stream(stream)
+        graph.replay()  # first replay uploads the graph
+        torch.cuda.synchronize()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        step()
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(args.steps):
+            step()
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -305,7 +328,7 @@ def main():
                        "cells_per_gpu": n, "sharding": "contiguous row-block per rank, no data-path collective",
                        "inputs": "splitmix64 counter streams generated on device, resident in HBM",
                        "kernel_variant": "lds" if (args.variant or 0) == 1 else "direct",
-                       "clock_ramp_steps": ramp},
+                       "clock_ramp_steps": ramp, "launch": "hipGraph of the K steps" if args.graph else "K stream launches"},
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": recorded_traffic(n) if (args.workload == "div_u8_u16" and world == 1) else None,
