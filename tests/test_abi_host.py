@@ -171,3 +171,28 @@ def test_rust_extern_block_declares_every_entry_point():
 
     assert set(c_decls) == set(r_decls), (sorted(set(c_decls) - set(r_decls)), sorted(set(r_decls) - set(c_decls)))
     assert {k: argc(v) for k, v in c_decls.items()} == {k: argc(v) for k, v in r_decls.items()}
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "quick_c")
+    libdir = os.path.join(ROOT, "erased-cells_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "quick.c"), "-L" + libdir, "-lerased_cells_hip",
+                        "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c99_and_links_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: the header compiles as pedantic C99 and a C program links against the .so."""
+    _build_c_example(tmp_path)
+
+
+@pytest.mark.gpu
+def test_quick_example_from_plain_c(tmp_path):
+    """examples/quick.rs:5-11 through the C ABI from C (examples/quick.c)."""
+    import subprocess
+    r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["0.25", "0.25", "0.25"]
