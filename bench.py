@@ -137,6 +137,8 @@ class _StdoutToStderr:
 
 def main():
     args = parse()
+    # the host driver of this pool only supports dmabuf IPC; RCCL fails without it (already exported on the boxes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 

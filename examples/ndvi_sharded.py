@@ -16,6 +16,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "erased-cells_amd", "python"))
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this pool
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
