@@ -51,8 +51,9 @@ __device__ __forceinline__ size_t two_front_tile() {
 }
 
 // ---------------------------------------------------------------------------
-// DIRECT variant: one block tile of kBlock*U pairs (2 cells each).  All pointers
-// 16-B aligned (the launcher checks, else the cell-wise kernel runs).
+// DIRECT variant: one block tile of kBlock*U pairs (2 cells each).  Pointers may sit
+// at any cell offset (under-aligned accesses, ec_device.hpp); the cell-wise kernels run
+// only when the "unaligned_vector" knob is off and a pointer is not 16-B aligned.
 // ---------------------------------------------------------------------------
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const R* __restrict__ r,

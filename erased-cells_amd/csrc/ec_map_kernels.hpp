@@ -8,8 +8,9 @@
 // touches one contiguous span.  A block tile is U such groups per lane, loads
 // first, then compute + stores; one workgroup per tile, straight-line, with
 // non-temporal loads and stores (every byte is touched once).  Ragged tails are
-// guarded in the last tile; unaligned pointers take the cell-wise kernel
-// (correct for any alignment, one cell per lane).
+// guarded in the last tile.  Pointers may sit at any cell offset (under-aligned
+// accesses, ec_device.hpp); the cell-wise kernel (one cell per lane) runs only
+// when the "unaligned_vector" knob is off and a pointer is not 16-B aligned.
 #pragma once
 
 #include "ec_binop_kernels.hpp"
