@@ -617,6 +617,12 @@ public:
     MaskedCellBuffer binop(ec_op op, const CellValue& rhs) const { return MaskedCellBuffer(buf_.binop(op, rhs), mask_.clone()); }
     MaskedCellBuffer neg() const { return MaskedCellBuffer(buf_.neg(), mask_.clone()); }
     bool operator==(const MaskedCellBuffer& o) const { return buf_ == o.buf_ && mask_ == o.mask_; }  // derived PartialEq (:39)
+    int cmp(const MaskedCellBuffer& o) const {  // derived PartialOrd (:39): buffer first, the mask breaks ties
+        const int c = buf_.cmp(o.buf_);
+        return c != 0 ? c : mask_.cmp(o.mask_);
+    }
+    bool operator<(const MaskedCellBuffer& o) const { return cmp(o) < 0; }
+    bool operator>(const MaskedCellBuffer& o) const { return cmp(o) > 0; }
     bool operator!=(const MaskedCellBuffer& o) const { return !(*this == o); }
 };
 

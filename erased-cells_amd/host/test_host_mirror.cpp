@@ -285,6 +285,12 @@ static void masked_tests() {
         buf.put_with_mask(5, CellValue(uint8_t(99)), false);
         CHECK(!buf.get_masked(5).has_value());
     }
+    {  // derived PartialOrd over (buffer, mask) (masked_buffer.rs:39)
+        MaskedCellBuffer a = MaskedCellBuffer::new_(CellBuffer::from_vec(std::vector<uint8_t>{1, 2, 3}), Mask::new_({true, false, true}));
+        MaskedCellBuffer b = MaskedCellBuffer::new_(CellBuffer::from_vec(std::vector<uint8_t>{1, 2, 3}), Mask::new_({true, true, true}));
+        MaskedCellBuffer c = MaskedCellBuffer::new_(CellBuffer::from_vec(std::vector<uint8_t>{1, 2, 4}), Mask::new_({false, false, false}));
+        CHECK(a.cmp(a) == 0 && a < b && b > a && b < c && a < c && !(c < a));
+    }
     {  // extend (masked_buffer.rs:449-455)
         MaskedCellBuffer buf = MaskedCellBuffer::fill(3, CellValue(0));
         buf.extend(std::vector<std::pair<int, bool>>{{1, false}});

@@ -659,6 +659,17 @@ class MaskedCellBuffer:
     def __eq__(self, other):  # derived PartialEq (masked_buffer.rs:39): buffer (all cells) and mask
         return isinstance(other, MaskedCellBuffer) and self._buf == other._buf and self._mask == other._mask
 
+    def cmp(self, other: "MaskedCellBuffer") -> int:
+        """derived PartialOrd (masked_buffer.rs:39): the buffer decides, the mask breaks ties; both on the device."""
+        c = self._buf.cmp(other._buf)
+        return c if c != 0 else self._mask.cmp(other._mask)
+
+    def __lt__(self, other):
+        return self.cmp(other) < 0
+
+    def __gt__(self, other):
+        return self.cmp(other) > 0
+
     __hash__ = None
 
     def __repr__(self):

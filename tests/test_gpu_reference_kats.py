@@ -79,6 +79,15 @@ def test_buffer_and_masked_extend(ec):
     assert e.to_numpy().tolist() == [1.5, 2.0] and e.cell_type() == ec.Float32
 
 
+def test_masked_buffer_ordering(ec):
+    """derived PartialOrd on MaskedCellBuffer(CellBuffer, Mask) (masked_buffer.rs:39): lexicographic over the pair."""
+    a = ec.MaskedCellBuffer(ec.CellBuffer.from_vec(np.array([1, 2, 3], np.uint8)), ec.Mask.new([True, False, True]))
+    b = ec.MaskedCellBuffer(ec.CellBuffer.from_vec(np.array([1, 2, 3], np.uint8)), ec.Mask.new([True, True, True]))
+    c = ec.MaskedCellBuffer(ec.CellBuffer.from_vec(np.array([1, 2, 4], np.uint8)), ec.Mask.new([False, False, False]))
+    assert a.cmp(a) == 0 and a < b and b > a and b < c and a < c and not (c < a)
+    assert a != b and a == ec.MaskedCellBuffer(a.buffer().clone(), a.mask().clone())
+
+
 def test_serde_wire_shapes_round_trip(ec):
     """serde's externally tagged shapes (parity unpinned — the reference holds no serialized
     fixture; see erased_cells_hip/wire.py)."""
