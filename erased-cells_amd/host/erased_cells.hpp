@@ -24,6 +24,7 @@
 #pragma once
 
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -53,6 +54,43 @@ enum class CellType : uint8_t { UInt8, UInt16, UInt32, UInt64, Int8, Int16, Int3
 inline const char* to_string(CellType ct) {
     static const char* n[] = {"UInt8", "UInt16", "UInt32", "UInt64", "Int8", "Int16", "Int32", "Int64", "Float32", "Float64"};
     return n[static_cast<int>(ct)];
+}
+
+// ---------------------------------------------------------------- Debug rendering (host only)
+// `format!("{:?}", x)` of a Rust primitive: integers plain; floats as the shortest digits that round-trip for
+// their width, decimal with at least one fractional digit for 1e-4 <= |x| < 1e16 (and zero), scientific
+// (`1e16`, `1.5e-7`) outside, `NaN` / `inf` / `-inf`; bools `true` / `false`.
+template <typename T> inline std::string rust_debug(T x) {
+    if constexpr (std::is_same<T, bool>::value) {
+        return x ? "true" : "false";
+    } else if constexpr (std::is_integral<T>::value) {
+        return std::to_string(+x);
+    } else {
+        if (x != x) return "NaN";
+        if (std::isinf(x)) return x > 0 ? "inf" : "-inf";
+        char buf[64];
+        const T ax = x < 0 ? -x : x;
+        if (ax == 0 || (ax >= T(1e-4) && ax < T(1e16))) {
+            auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::fixed);  // shortest round-trip digits
+            std::string out(buf, r.ptr);
+            if (out.find('.') == std::string::npos) out += ".0";
+            return out;
+        }
+        auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::scientific);
+        std::string sci(buf, r.ptr);  // d[.ddd]e[+-]XX
+        const size_t e = sci.find('e');
+        return sci.substr(0, e) + "e" + std::to_string(std::stoi(sci.substr(e + 1)));
+    }
+}
+// `Elided` (src/lib.rs:165-192): more than 10 items render as the first five, `, ... `, the last five.
+inline std::string elided(const std::vector<std::string>& items) {
+    std::string out;
+    auto join = [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i) { if (i > a) out += ", "; out += items[i]; }
+    };
+    if (items.size() > 10) { join(0, 5); out += ", ... "; join(items.size() - 5, items.size()); }
+    else join(0, items.size());
+    return out;
 }
 inline std::vector<CellType> cell_types() {  // CellType::iter (ctype.rs:47-52)
     std::vector<CellType> v;
@@ -301,6 +339,23 @@ public:
     size_t len() const { return n_; }
     bool is_empty() const { return n_ == 0; }
     CellType cell_type() const { return ct_; }
+    // impl Debug for CellBuffer (buffer.rs:188-203); only the cells that are shown cross the bus
+    std::string debug_string() const {
+        std::vector<std::string> items;
+        const size_t sz = size_of(ct_);
+        auto fetch = [&](size_t off, size_t k) {
+            std::vector<unsigned char> raw(k * sz);
+            if (k) check(ec_download(raw.data(), static_cast<const char*>(ptr()) + off * sz, raw.size(), current_stream()));
+            for (size_t i = 0; i < k; ++i) switch (ct_) {
+#define EC_DBG(ID, P) case CellType::ID: { P v; std::memcpy(&v, raw.data() + i * sz, sz); items.push_back(rust_debug<P>(v)); break; }
+                EC_HOST_WITH_CT(EC_DBG)
+#undef EC_DBG
+            }
+        };
+        if (n_ > 10) { fetch(0, 5); items.resize(11); fetch(n_ - 5, 5); }  // elided() drops the middle anyway
+        else fetch(0, n_);
+        return std::string(to_string(ct_)) + "CellBuffer(" + elided(items) + ")";
+    }
     CellBuffer clone() const {
         CellBuffer b(ct_, n_);
         check(ec_copy(b.ptr(), ptr(), n_ * size_of(ct_), current_stream()));
@@ -486,6 +541,17 @@ public:
     }
     bool operator==(const Mask& o) const { return cmp(o) == 0; }
     bool operator!=(const Mask& o) const { return !(*this == o); }
+    std::string debug_string() const {  // impl Debug for Mask (mask.rs:165-169)
+        std::vector<std::string> items;
+        auto fetch = [&](size_t off, size_t k) {
+            std::vector<uint8_t> raw(k);
+            if (k) check(ec_download(raw.data(), ptr() + off, k, current_stream()));
+            for (uint8_t b : raw) items.push_back(rust_debug<bool>(b != 0));
+        };
+        if (n_ > 10) { fetch(0, 5); items.resize(11); fetch(n_ - 5, 5); }
+        else fetch(0, n_);
+        return "Mask(" + elided(items) + ")";
+    }
 
     Mask operator!() const& {  // Not for &Mask (mask.rs:111-116)
         Mask m(n_);
@@ -617,6 +683,9 @@ public:
     MaskedCellBuffer binop(ec_op op, const CellValue& rhs) const { return MaskedCellBuffer(buf_.binop(op, rhs), mask_.clone()); }
     MaskedCellBuffer neg() const { return MaskedCellBuffer(buf_.neg(), mask_.clone()); }
     bool operator==(const MaskedCellBuffer& o) const { return buf_ == o.buf_ && mask_ == o.mask_; }  // derived PartialEq (:39)
+    std::string debug_string() const {  // debug_tuple(buffer, mask) (:227-235)
+        return std::string(to_string(cell_type())) + "MaskedCellBuffer(" + buf_.debug_string() + ", " + mask_.debug_string() + ")";
+    }
     int cmp(const MaskedCellBuffer& o) const {  // derived PartialOrd (:39): buffer first, the mask breaks ties
         const int c = buf_.cmp(o.buf_);
         return c != 0 ? c : mask_.cmp(o.mask_);

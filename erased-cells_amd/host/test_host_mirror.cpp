@@ -212,6 +212,15 @@ static void buffer_tests() {
         CHECK(wd(4, CellType::UInt8) < wd(4, CellType::Float32) && wd(4, CellType::Float32) > wd(4, CellType::UInt8));
         CHECK(wd(4, CellType::UInt8) < wd(5, CellType::UInt8) && wd(5, CellType::Float64) > wd(4, CellType::Float64));
     }
+    {  // debug (buffer.rs:558-564), elided (lib.rs:197-206)
+        CHECK(elided(std::vector<std::string>(3, "1")) == "1, 1, 1");
+        CHECK(elided(std::vector<std::string>(30, "0")) == "0, 0, 0, 0, 0, ... 0, 0, 0, 0, 0");
+        CellBuffer b = CellBuffer::fill(5, CellValue(37));
+        CHECK(b.debug_string() == "Int32CellBuffer(37, 37, 37, 37, 37)");
+        b = CellBuffer::fill(15, CellValue(37));
+        CHECK(b.debug_string() == "Int32CellBuffer(37, 37, 37, 37, 37, ... 37, 37, 37, 37, 37)");
+        CHECK(CellBuffer::from_vec(std::vector<float>{0.5f, 2.0f}).debug_string() == "Float32CellBuffer(0.5, 2.0)");
+    }
     {  // extend (buffer.rs:489-498)
         CellBuffer buf = CellBuffer::fill(3, CellValue(uint8_t(0)));
         CHECK(!buf.is_empty() && buf.cell_type() == CellType::UInt8);
@@ -284,6 +293,10 @@ static void masked_tests() {
         CHECK(buf.get_masked(5) == CellValue(4));
         buf.put_with_mask(5, CellValue(uint8_t(99)), false);
         CHECK(!buf.get_masked(5).has_value());
+    }
+    {  // debug (masked_buffer.rs:533-540)
+        MaskedCellBuffer m = MaskedCellBuffer::from_vec(std::vector<int32_t>{0});
+        CHECK(m.debug_string() == "Int32MaskedCellBuffer(Int32CellBuffer(0), Mask(true))");
     }
     {  // derived PartialOrd over (buffer, mask) (masked_buffer.rs:39)
         MaskedCellBuffer a = MaskedCellBuffer::new_(CellBuffer::from_vec(std::vector<uint8_t>{1, 2, 3}), Mask::new_({true, false, true}));
@@ -405,12 +418,22 @@ static void gdal_tests(const std::string& data_dir) {
     CHECK_THROWS(Error, RasterBand::open(path("does-not-exist.tiff")));
 }
 
+static void debug_format_checks() {  // Rust `{:?}` of floats; no device needed
+    CHECK(rust_debug(0.25) == "0.25" && rust_debug(37.0) == "37.0" && rust_debug(-0.0) == "-0.0");
+    CHECK(rust_debug(1e-7) == "1e-7" && rust_debug(1e16) == "1e16" && rust_debug(1.5e300) == "1.5e300");
+    CHECK(rust_debug(123456789012345680.0) == "1.2345678901234568e17" && rust_debug(0.0001) == "0.0001" && rust_debug(0.00001) == "1e-5");
+    CHECK(rust_debug(0.1f) == "0.1" && rust_debug(16777216.0f) == "16777216.0" && rust_debug(1e-10f) == "1e-10");
+    CHECK(rust_debug(std::nan("")) == "NaN" && rust_debug(INFINITY) == "inf" && rust_debug(-HUGE_VAL) == "-inf");
+    CHECK(rust_debug<int8_t>(-5) == "-5" && rust_debug<uint8_t>(200) == "200" && rust_debug<uint64_t>(18446744073709551615ull) == "18446744073709551615");
+}
+
 int main(int argc, char** argv) {
     bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
     const char* dd = std::getenv("TEST_DATA_DIR");  // as the reference's testkit (.cargo/config.toml:3)
     try {
         ctype_tests();
         value_tests();
+        debug_format_checks();
         if (!host_only) {
             init(0);
             nodata_tests();

@@ -68,6 +68,48 @@ def can_fit_into(a: int, b: int) -> bool:
 
 
 # --------------------------------------------------------------------------- CellValue
+def rust_debug(x) -> str:
+    """`format!("{:?}", x)` of a Rust primitive: integers plain; floats as the shortest digits that round-trip
+    for their width, decimal with at least one fractional digit for 1e-4 <= |x| < 1e16 (and zero), scientific
+    (`1e16`, `1.5e-7`) outside, `NaN` / `inf` / `-inf`; bools `true` / `false`."""
+    if isinstance(x, (bool, np.bool_)):
+        return "true" if x else "false"
+    if isinstance(x, (int, np.integer)):
+        return str(int(x))
+    x = x if isinstance(x, np.floating) else np.float64(x)
+    if np.isnan(x):
+        return "NaN"
+    if np.isinf(x):
+        return "inf" if x > 0 else "-inf"
+    ax = abs(float(x))
+    if ax == 0.0 or 1e-4 <= ax < 1e16:
+        return np.format_float_positional(x, unique=True, trim="0")
+    mant, exp = np.format_float_scientific(x, unique=True, trim="-").split("e")
+    return f"{mant}e{int(exp)}"
+
+
+def elided(values) -> str:
+    """`Elided` (src/lib.rs:165-192): more than 10 items render as the first five, `, ... `, the last five."""
+    items = [rust_debug(v) for v in values]
+    if len(items) > 10:
+        return ", ".join(items[:5]) + ", ... " + ", ".join(items[-5:])
+    return ", ".join(items)
+
+
+def _ends(n: int, fetch):
+    """The cells a Debug rendering shows: all of them up to 10, else only the first and last five are downloaded."""
+    if n <= 10:
+        return list(fetch(0, n))
+    return list(fetch(0, 5)) + [None] + list(fetch(n - 5, 5))
+
+
+def _elided_ends(n: int, fetch) -> str:
+    vals = _ends(n, fetch)
+    if n > 10:
+        return elided(vals[:5]) + ", ... " + elided(vals[6:])
+    return elided(vals)
+
+
 class CellValue:
     """Scalar with a run-time cell type (src/value.rs:12-20)."""
 
@@ -153,8 +195,8 @@ class CellValue:
     def __hash__(self):
         return hash((self.ct, self.bits()))
 
-    def __repr__(self):
-        return f"{CT_NAMES[self.ct]}({self.value!r})"
+    def __repr__(self):  # derived Debug: `Int32(37)`
+        return f"{CT_NAMES[self.ct]}({rust_debug(self.value)})"
 
 
 # --------------------------------------------------------------------------- device memory
@@ -373,8 +415,8 @@ class CellBuffer:
 
     __hash__ = None
 
-    def __repr__(self):
-        return f"{CT_NAMES[self.ct]}CellBuffer(len={self.n})"
+    def __repr__(self):  # impl Debug for CellBuffer (src/buffer.rs:188-203)
+        return f"{CT_NAMES[self.ct]}CellBuffer({_elided_ends(self.n, lambda o, k: self.shard(o, k).to_numpy())})"
 
 
 # --------------------------------------------------------------------------- NoData
@@ -521,8 +563,8 @@ class Mask:
 
     __hash__ = None
 
-    def __repr__(self):
-        return f"Mask(len={self.n})"
+    def __repr__(self):  # impl Debug for Mask (src/masked/mask.rs:165-169)
+        return f"Mask({_elided_ends(self.n, lambda o, k: self.shard(o, k).to_numpy().astype(bool))})"
 
 
 # --------------------------------------------------------------------------- MaskedCellBuffer
@@ -672,8 +714,8 @@ class MaskedCellBuffer:
 
     __hash__ = None
 
-    def __repr__(self):
-        return f"{CT_NAMES[self.cell_type()]}MaskedCellBuffer(len={self.len()})"
+    def __repr__(self):  # debug_tuple(buffer, mask) (src/masked/masked_buffer.rs:227-235)
+        return f"{CT_NAMES[self.cell_type()]}MaskedCellBuffer({self._buf!r}, {self._mask!r})"
 
 
 MaskedCellBuffer.new = staticmethod(lambda buffer, mask: MaskedCellBuffer(buffer, mask))

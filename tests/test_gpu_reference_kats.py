@@ -79,6 +79,28 @@ def test_buffer_and_masked_extend(ec):
     assert e.to_numpy().tolist() == [1.5, 2.0] and e.cell_type() == ec.Float32
 
 
+def test_debug_rendering(ec):
+    """src/lib.rs:197-206 (elided), src/buffer.rs:558-564 and src/masked/masked_buffer.rs:533-540 (debug)."""
+    from erased_cells_hip.buffer import elided, rust_debug
+    assert elided([1] * 3) == "1, 1, 1"
+    assert elided([0] * 30) == "0, 0, 0, 0, 0, ... 0, 0, 0, 0, 0"
+    b = ec.CellBuffer.fill(5, 37)
+    assert repr(b).startswith("Int32CellBuffer") and repr(b) == "Int32CellBuffer(37, 37, 37, 37, 37)"
+    b = ec.CellBuffer.fill(15, 37)
+    assert "..." in repr(b) and repr(b) == "Int32CellBuffer(37, 37, 37, 37, 37, ... 37, 37, 37, 37, 37)"
+    m = ec.MaskedCellBuffer.from_vec(np.arange(0, 1, dtype=np.int32))
+    dbg = repr(m)
+    assert dbg.startswith("Int32MaskedCellBuffer") and "CellBuffer(0)" in dbg and "Mask(true)" in dbg
+    assert dbg == "Int32MaskedCellBuffer(Int32CellBuffer(0), Mask(true))"
+    # Rust `{:?}` of floats: shortest round-trip digits, `.0` on integral values, scientific outside [1e-4, 1e16)
+    got = [rust_debug(np.float64(x)) for x in (0.25, 37.0, -0.0, 1e-7, 1e16, 1.5e300, 123456789012345680.0, 0.0001, 0.00001)]
+    assert got == ["0.25", "37.0", "-0.0", "1e-7", "1e16", "1.5e300", "1.2345678901234568e17", "0.0001", "1e-5"]
+    assert [rust_debug(np.float32(x)) for x in (0.1, 16777216.0, 1e-10)] == ["0.1", "16777216.0", "1e-10"]
+    assert [rust_debug(x) for x in (np.float64("nan"), np.float32("inf"), -np.float64("inf"))] == ["NaN", "inf", "-inf"]
+    assert repr(ec.CellBuffer.from_vec(np.array([0.5, 2.0], np.float32))) == "Float32CellBuffer(0.5, 2.0)"
+    assert repr(ec.CellValue.new(37)) == "Int32(37)" and repr(ec.CellBuffer.empty(0, ec.UInt8)) == "UInt8CellBuffer()"
+
+
 def test_masked_buffer_ordering(ec):
     """derived PartialOrd on MaskedCellBuffer(CellBuffer, Mask) (masked_buffer.rs:39): lexicographic over the pair."""
     a = ec.MaskedCellBuffer(ec.CellBuffer.from_vec(np.array([1, 2, 3], np.uint8)), ec.Mask.new([True, False, True]))
