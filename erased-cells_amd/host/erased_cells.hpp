@@ -325,6 +325,28 @@ public:
         return b;
     }
     template <typename T> static CellBuffer new_(const std::vector<T>& data) { return from_vec(data); }
+    // impl FromIterator<CellValue> (buffer.rs:229-250): empty -> UInt8; else the FIRST value's type, every
+    // value through get::<T>().unwrap() (NarrowingError when one does not fit)
+    static CellBuffer from_values(const std::vector<CellValue>& values) {
+        if (values.empty()) return empty_u8();
+        const CellType ct = values[0].cell_type();
+        switch (ct) {
+#define EC_FV(ID, P) case CellType::ID: { std::vector<P> v; for (const auto& x : values) v.push_back(x.get<P>()); return from_vec(v); }
+            EC_HOST_WITH_CT(EC_FV)
+#undef EC_FV
+        }
+        return empty_u8();
+    }
+    // impl IntoIterator for &CellBuffer (buffer.rs:278-305), as one download
+    std::vector<CellValue> to_values() const {
+        std::vector<CellValue> out;
+        switch (ct_) {
+#define EC_TV(ID, P) case CellType::ID: { for (P x : to_vec<P>()) out.emplace_back(x); break; }
+            EC_HOST_WITH_CT(EC_TV)
+#undef EC_TV
+        }
+        return out;
+    }
     static CellBuffer with_defaults(size_t len, CellType ct) { return fill(len, zero(ct)); }  // buffer.rs:68-77
     static CellBuffer fill(size_t len, const CellValue& value) {                              // buffer.rs:79-88
         CellBuffer b(value.cell_type(), len);

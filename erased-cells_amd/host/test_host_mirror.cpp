@@ -212,6 +212,17 @@ static void buffer_tests() {
         CHECK(wd(4, CellType::UInt8) < wd(4, CellType::Float32) && wd(4, CellType::Float32) > wd(4, CellType::UInt8));
         CHECK(wd(4, CellType::UInt8) < wd(5, CellType::UInt8) && wd(5, CellType::Float64) > wd(4, CellType::Float64));
     }
+    {  // from_others (buffer.rs:528-555)
+        CellBuffer b = CellBuffer::from_values({CellValue(uint16_t(3)), CellValue(uint16_t(4)), CellValue(uint16_t(5))});
+        CHECK(b.cell_type() == CellType::UInt16 && b.len() == 3 && b.get(2) == CellValue(uint16_t(5)));
+        b = CellBuffer::from_vec(std::vector<float>{33.3f, 44.4f, 55.5f});
+        CHECK(b.cell_type() == CellType::Float32 && b.len() == 3 && b.get(2) == CellValue(55.5f));
+        CHECK(CellBuffer::from_values({}).cell_type() == CellType::UInt8);
+        CHECK(CellBuffer::from_values({CellValue(int32_t(7)), CellValue(uint8_t(9))}).to_vec<int32_t>() == (std::vector<int32_t>{7, 9}));
+        CHECK_THROWS(NarrowingError, CellBuffer::from_values({CellValue(uint8_t(7)), CellValue(int32_t(9))}));
+        auto vals = b.to_values();
+        CHECK(vals.size() == 3 && vals[0] == CellValue(33.3f) && vals[2] == CellValue(55.5f));
+    }
     {  // debug (buffer.rs:558-564), elided (lib.rs:197-206)
         CHECK(elided(std::vector<std::string>(3, "1")) == "1, 1, 1");
         CHECK(elided(std::vector<std::string>(30, "0")) == "0, 0, 0, 0, 0, ... 0, 0, 0, 0, 0");

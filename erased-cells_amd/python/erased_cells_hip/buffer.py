@@ -265,6 +265,20 @@ class CellBuffer:
     new = from_vec
 
     @staticmethod
+    def from_values(values) -> "CellBuffer":
+        """impl FromIterator<CellValue> for CellBuffer (src/buffer.rs:229-250): empty -> UInt8; otherwise the
+        FIRST value's cell type, every value through `get::<T>().unwrap()` (a value that does not fit panics)."""
+        vals = [CellValue.new(v) for v in values]
+        if not vals:
+            return CellBuffer.with_defaults(0, UInt8)
+        ct = vals[0].ct
+        return CellBuffer.from_vec(np.array([v.get(ct) for v in vals], dtype=NP_DTYPES[ct]))
+
+    def __iter__(self):
+        """impl IntoIterator for &CellBuffer (src/buffer.rs:278-305): yields CellValue; one download for the walk."""
+        return (CellValue(self.ct, v) for v in self.to_numpy())
+
+    @staticmethod
     def with_defaults(length: int, ct: int) -> "CellBuffer":
         return CellBuffer.fill(length, CellValue(ct, 0))
 
@@ -504,6 +518,15 @@ class Mask:
         a = np.array([1 if value else 0], dtype=np.uint8)
         check(lib().ec_upload(self.mem.window(index, 1).ptr, a.ctypes.data_as(C.c_void_p), 1, _stream))
 
+    def __iter__(self):  # impl IntoIterator for Mask (mask.rs:171-178)
+        return (bool(b) for b in self.to_numpy())
+
+    def __getitem__(self, index: int) -> bool:  # impl Index<usize> for Mask (mask.rs:89-94)
+        return self.get(index)
+
+    def __setitem__(self, index: int, value: bool) -> None:  # impl IndexMut (mask.rs:96-100)
+        self.put(index, value)
+
     def extend(self, values) -> None:  # impl Extend<bool> for Mask (mask.rs:83-87)
         new = np.asarray([bool(v) for v in values], dtype=np.uint8)
         grown = DeviceMem(self.n + new.size)
@@ -582,6 +605,21 @@ class MaskedCellBuffer:
     def from_vec(data) -> "MaskedCellBuffer":
         b = CellBuffer.from_vec(data)
         return MaskedCellBuffer(b, Mask.fill(b.len(), True))
+
+    @staticmethod
+    def from_iter(items, dtype=None) -> "MaskedCellBuffer":
+        """FromIterator<C> (all valid) and FromIterator<(C, bool)> for MaskedCellBuffer (masked_buffer.rs:257-278)."""
+        items = list(items)
+        if items and isinstance(items[0], tuple):
+            vals = np.array([p[0] for p in items]) if dtype is None else np.array([p[0] for p in items], dtype=dtype)
+            if vals.dtype == np.dtype(np.int64) and dtype is None:
+                vals = vals.astype(np.int32)
+            return MaskedCellBuffer(CellBuffer.from_vec(vals), Mask.new([bool(p[1]) for p in items]))
+        return MaskedCellBuffer.from_vec(items if dtype is None else np.array(items, dtype=dtype))
+
+    def __iter__(self):
+        """impl IntoIterator for &MaskedCellBuffer (masked_buffer.rs:289-318): yields (CellValue, bool)."""
+        return ((CellValue(self.cell_type(), v), bool(m)) for v, m in zip(self._buf.to_numpy(), self._mask.to_numpy()))
 
     @staticmethod
     def from_buffer(b: CellBuffer) -> "MaskedCellBuffer":  # From<CellBuffer> (masked_buffer.rs:250-255)

@@ -79,6 +79,32 @@ def test_buffer_and_masked_extend(ec):
     assert e.to_numpy().tolist() == [1.5, 2.0] and e.cell_type() == ec.Float32
 
 
+def test_from_others_and_iterators(ec):
+    """src/buffer.rs:528-555 (from_others), src/masked/masked_buffer.rs:457-462 (from_iter), the IntoIterator impls."""
+    b = ec.CellBuffer.from_values([ec.CellValue(ec.UInt16, x) for x in (3, 4, 5)])
+    assert b.cell_type() == ec.UInt16 and b.len() == 3 and b.get(2) == ec.CellValue(ec.UInt16, 5)
+    v = np.array([33.3, 44.4, 55.5], np.float32)
+    b = ec.CellBuffer.from_values([ec.CellValue.new(x) for x in v])
+    assert b.cell_type() == ec.Float32 and b.len() == 3 and b.get(2) == ec.CellValue(ec.Float32, np.float32(55.5))
+    b = ec.CellBuffer.from_vec(v)
+    assert b.cell_type() == ec.Float32 and b.len() == 3 and b.get(2) == ec.CellValue(ec.Float32, np.float32(55.5))
+    assert ec.CellBuffer.from_values([]).cell_type() == ec.UInt8
+    # the first value decides the type; later values go through get::<T>().unwrap()
+    mixed = ec.CellBuffer.from_values([ec.CellValue(ec.Int32, 7), ec.CellValue(ec.UInt8, 9)])
+    assert mixed.cell_type() == ec.Int32 and mixed.to_numpy().tolist() == [7, 9]
+    with pytest.raises(ec.NarrowingError):
+        ec.CellBuffer.from_values([ec.CellValue(ec.UInt8, 7), ec.CellValue(ec.Int32, 9)])
+    assert list(b) == [ec.CellValue(ec.Float32, x) for x in v]
+    buf = ec.MaskedCellBuffer.from_iter(range(5), dtype=np.int16)
+    assert buf.mask().all(True) and buf.to_vec(ec.Int16).tolist() == [0, 1, 2, 3, 4]
+    pairs = ec.MaskedCellBuffer.from_iter([(1, True), (2, False)], dtype=np.uint8)
+    assert list(pairs) == [(ec.CellValue(ec.UInt8, 1), True), (ec.CellValue(ec.UInt8, 2), False)]
+    m = ec.Mask.new([True, False, True])
+    assert list(m) == [True, False, True] and m[1] is False
+    m[1] = True
+    assert m.all(True)
+
+
 def test_debug_rendering(ec):
     """src/lib.rs:197-206 (elided), src/buffer.rs:558-564 and src/masked/masked_buffer.rs:533-540 (debug)."""
     from erased_cells_hip.buffer import elided, rust_debug
