@@ -195,6 +195,46 @@ class CellValue:
     def __hash__(self):
         return hash((self.ct, self.bits()))
 
+    def __gt__(self, other):
+        return self.cmp(CellValue.new(other)) > 0
+
+    def unify(self, other: "CellValue") -> tuple["CellValue", "CellValue"]:
+        """value.rs:103-107: both converted to the union of their cell types."""
+        ct = union(self.ct, other.ct)
+        return self.convert(ct), other.convert(ct)
+
+    @staticmethod
+    def zero() -> "CellValue":  # num_traits::Zero (value.rs:166-170)
+        return CellValue(UInt8, 0)
+
+    @staticmethod
+    def one() -> "CellValue":  # num_traits::One (value.rs:159-164)
+        return CellValue(UInt8, 1)
+
+    def is_zero(self) -> bool:  # value.rs:172-174
+        return self.to_f64() == 0.0
+
+    def _scalar_op(self, other, fn) -> "CellValue":
+        """cv_bin_op! (value.rs:199-217): both sides as f64, result always Float64.  Scalar arithmetic stays on the
+        host as in the reference (IEEE double arithmetic of the host CPU; the buffers' per-cell form runs on the GPU)."""
+        a, b = np.float64(self.to_f64()), np.float64(CellValue.new(other).to_f64())
+        with np.errstate(all="ignore"):
+            return CellValue(Float64, fn(a, b))
+
+    def __add__(self, other): return self._scalar_op(other, lambda a, b: a + b)
+    def __sub__(self, other): return self._scalar_op(other, lambda a, b: a - b)
+    def __mul__(self, other): return self._scalar_op(other, lambda a, b: a * b)
+    def __truediv__(self, other): return self._scalar_op(other, lambda a, b: a / b)
+
+    def __neg__(self) -> "CellValue":
+        """impl Neg for CellValue (value.rs:224-240): u8 -> i16, u16 -> i32, u32/u64 -> f64, signed wrap, floats flip."""
+        out_ct = lib().ec_neg_result_type(self.ct)
+        dt = NP_DTYPES[out_ct]
+        with np.errstate(all="ignore"):
+            if dt.kind == "f":
+                return CellValue(out_ct, -dt.type(self.value))
+            return CellValue(out_ct, (np.array([self.value]).astype(dt) * dt.type(-1))[0])  # wrapping at MIN
+
     def __repr__(self):  # derived Debug: `Int32(37)`
         return f"{CT_NAMES[self.ct]}({rust_debug(self.value)})"
 

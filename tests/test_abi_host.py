@@ -4,6 +4,7 @@ oracle (and so with src/ctype.rs), and compute calls fail loudly — never fall
 back — when no HIP device is bound."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -196,3 +197,35 @@ def test_quick_example_from_plain_c(tmp_path):
     r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout.split() == ["0.25", "0.25", "0.25"]
+
+
+def test_cell_value_scalar_semantics_reference_tests():
+    """src/value.rs:283-360 restated on the Python mirror's CellValue (host-only: lattice functions of the library)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "erased-cells_amd", "python"))
+    import erased_cells_hip as ec
+    CV = ec.CellValue
+    for ct in ec.CELL_TYPES:  # cell_type(), get()
+        cv = CV(ct, 0)
+        assert cv.cell_type() == ct and cv.get(ct) == 0 and cv.get(ec.Float64) == 0.0
+    assert CV(ec.UInt8, 43).convert(ec.Int16) == CV(ec.Int16, 43) and CV(ec.UInt8, 43).convert(ec.Int16).cell_type() == ec.Int16
+    with pytest.raises(ec.NarrowingError):
+        CV(ec.Float32, 3.11111).convert(ec.Int32)
+    assert CV(ec.Float32, 3.11111).convert(ec.Float32) == CV(ec.Float32, 3.11111)
+    r = CV(ec.UInt16, 33).convert(ec.Float32)
+    assert r.cell_type() == ec.Float32 and r.value == np.float32(33.0)
+    assert CV.zero().is_zero() and not CV.one().is_zero()
+    for (ct, v), (ect, ev) in [((ec.UInt8, 1), (ec.Int16, -1)), ((ec.UInt16, 1), (ec.Int32, -1)), ((ec.Int8, 1), (ec.Int8, -1)),
+                               ((ec.Int16, 1), (ec.Int16, -1)), ((ec.Float64, 1.0), (ec.Float64, -1.0)),
+                               ((ec.Float32, 1.0), (ec.Float32, -1.0)), ((ec.UInt32, 5), (ec.Float64, -5.0)),
+                               ((ec.Int8, -128), (ec.Int8, -128))]:
+        n = -CV(ct, v)
+        assert n.cell_type() == ect and n.value == ev
+    for ct in (ec.UInt8, ec.UInt16, ec.Int64, ec.Float32):  # binops: always Float64
+        l, r = CV(ct, 1), CV(ct, 2)
+        for got, exp in [(l + r, 3.0), (l + 2, 3.0), (l - r, -1.0), (l - 2, -1.0), (r - l, 1.0), (l * r, 2.0), (r * l, 2.0),
+                         (l / r, 0.5), (r / l, 2.0)]:
+            assert got.cell_type() == ec.Float64 and got == CV(ec.Float64, exp)
+    a, b = CV(ec.UInt8, 3).unify(CV(ec.Int8, -3))
+    assert a.cell_type() == b.cell_type() == ec.Int16 and (a.value, b.value) == (3, -3)
+    assert CV(ec.UInt8, 3) < CV(ec.Float32, 3.5) and CV(ec.Int64, 4) > CV(ec.UInt8, 3)
