@@ -9,7 +9,8 @@ from . import _ffi, fused, raster, wire
 from ._ffi import EcError, NarrowingError, build, lib
 from .buffer import (ADD, CELL_TYPES, CT_NAMES, DIV, MUL, NP_DTYPES, SUB, CellBuffer, CellValue, DeviceMem,
                      Float32, Float64, Int8, Int16, Int32, Int64, Mask, MaskedCellBuffer, NoData, UInt8,
-                     UInt16, UInt32, UInt64, can_fit_into, cell_type_of, init, mask_from_nodata, set_stream,
-                     stream, synchronize, union)
+                     UInt16, UInt32, UInt64, ParseError, can_fit_into, cell_type_from_str, cell_type_of,
+                     cell_type_to_string, init, is_integral, is_signed, mask_from_nodata, max_value, min_value, one,
+                     set_stream, size_of, stream, synchronize, union, zero)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -67,6 +67,53 @@ def can_fit_into(a: int, b: int) -> bool:
     return bool(lib().ec_can_fit_into(a, b))
 
 
+class ParseError(ValueError):
+    """Error::ParseError (src/error.rs, raised by `CellType::from_str`, src/ctype.rs:29-44)."""
+
+
+def cell_type_to_string(ct: int) -> str:  # Display == Debug (ctype.rs:22-27)
+    return CT_NAMES[ct]
+
+
+def cell_type_from_str(s: str) -> int:  # ctype.rs:29-44
+    for ct in CELL_TYPES:
+        if CT_NAMES[ct] == s:
+            return ct
+    raise ParseError(f"Unable to parse '{s}' as CellType")
+
+
+def is_integral(ct: int) -> bool:  # ctype.rs:55-69
+    return NP_DTYPES[ct].kind in "ui"
+
+
+def is_signed(ct: int) -> bool:  # ctype.rs:71-85
+    return NP_DTYPES[ct].kind in "if"
+
+
+def size_of(ct: int) -> int:  # ctype.rs:87-96
+    return lib().ec_size_of(ct)
+
+
+def min_value(ct: int) -> "CellValue":  # ctype.rs:158-167
+    out = EcValue()
+    check(lib().ec_min_value(ct, C.byref(out)))
+    return CellValue.from_ec(out)
+
+
+def max_value(ct: int) -> "CellValue":  # ctype.rs:170-179
+    out = EcValue()
+    check(lib().ec_max_value(ct, C.byref(out)))
+    return CellValue.from_ec(out)
+
+
+def zero(ct: int) -> "CellValue":  # ctype.rs:134-144
+    return CellValue(ct, 0)
+
+
+def one(ct: int) -> "CellValue":  # ctype.rs:146-156
+    return CellValue(ct, 1)
+
+
 # --------------------------------------------------------------------------- CellValue
 def rust_debug(x) -> str:
     """`format!("{:?}", x)` of a Rust primitive: integers plain; floats as the shortest digits that round-trip
