@@ -13,8 +13,14 @@ namespace ecd {
 // Compile-time launch shape of the binary-arithmetic kernels; chosen from the
 // A/B runs recorded in profiles/ (tools/tune_binop.hip).
 constexpr int kBinopU = 2;         // chunks of 128 cells per wave per tile (U = 2 beats 8 by ≈6 %: tune_binop_v4/v5.log)
-constexpr bool kNtStore = true;    // streaming f64 output: 2.1 GB ≫ 256 MiB Infinity Cache
-constexpr bool kNtLoad = true;     // +6 % on the divide (tune_binop_v2.log: 6270 -> 6666 GB/s)
+#ifndef EC_NT_STORE
+#define EC_NT_STORE 1  // build-time A/B switch (make EXTRA=-DEC_NT_STORE=0)
+#endif
+#ifndef EC_NT_LOAD
+#define EC_NT_LOAD 1
+#endif
+constexpr bool kNtStore = EC_NT_STORE;    // streaming f64 output: 2.1 GB ≫ 256 MiB Infinity Cache
+constexpr bool kNtLoad = EC_NT_LOAD;     // +6 % on the divide (tune_binop_v2.log: 6270 -> 6666 GB/s)
 constexpr int kReduceU = 4;
 constexpr int kMaxReduceBlocks = 4096;
 

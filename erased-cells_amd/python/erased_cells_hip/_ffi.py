@@ -12,7 +12,7 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 AMD_DIR = os.path.dirname(os.path.dirname(_PKG))          # erased-cells_amd/
 REPO = os.path.dirname(AMD_DIR)
-SO_PATH = os.path.join(AMD_DIR, "liberased_cells_hip.so")
+SO_PATH = os.environ.get("EC_HIP_LIB") or os.path.join(AMD_DIR, "liberased_cells_hip.so")  # EC_HIP_LIB: A/B builds
 CSRC = os.path.join(AMD_DIR, "csrc")
 
 EC_OK, EC_ERR_NARROWING, EC_ERR_UNSUPPORTED_TYPE, EC_ERR_LENGTH, EC_ERR_HIP, EC_ERR_RCCL, EC_ERR_ARG, \
