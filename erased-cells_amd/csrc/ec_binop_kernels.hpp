@@ -87,12 +87,12 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
         for (int j = 0; j < U; ++j) {
             const size_t p = base + size_t(j) * kBlock;
             if (p < npairs) {
-                L2 a = lp[p];
-                R2 b = rp[p];
+                L2 a = plain_load(lp + p);
+                R2 b = plain_load(rp + p);
                 D2 o;
                 o.x = cell_op<OP, FP>(to_f64(a.x), to_f64(b.x));
                 o.y = cell_op<OP, FP>(to_f64(a.y), to_f64(b.y));
-                op[p] = o;
+                plain_store(o, op + p);
             }
         }
     }
@@ -101,10 +101,21 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
 // One block per tile, straight-line: no grid-stride loop (profiles/r01/tune_binop_v2.log — the
 // loop-free form runs ≈5 % faster than a grid capped at a few blocks per CU).  The grid must be
 // exactly ceil(npairs / TILE) workgroups (two_front_tile is a permutation of the tile indices).
+// `head` (0 or 1, chosen by the launcher: peel_head() in ec_runtime.hpp) leading cells are computed one by
+// one by workgroup 0 and the pair grid starts after them, so that the 2-cell loads of 1- and 2-byte operands
+// fall on even cell indices: a u8x2 load at an odd address or a u16x2 load at 2 mod 4 runs ≈8 % slower
+// (profiles/r01/unaligned_windows.md), while the f64 pair store does not mind being 8 bytes off.
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const R* __restrict__ r,
-                                                  double* __restrict__ out, size_t n) {
+                                                  double* __restrict__ out, size_t n, unsigned head) {
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    if (head) {
+        if (blockIdx.x == 0 && threadIdx.x < head) out[threadIdx.x] = cell_op<OP, FP>(to_f64(l[threadIdx.x]), to_f64(r[threadIdx.x]));
+        l += head;
+        r += head;
+        out += head;
+        n -= head;
+    }
     binop_direct_tile<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n >> 1, two_front_tile());
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
         out[n - 1] = cell_op<OP, FP>(to_f64(l[n - 1]), to_f64(r[n - 1]));
@@ -136,11 +147,11 @@ __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, doubl
         for (int j = 0; j < U; ++j) {
             const size_t p = base + size_t(j) * kBlock;
             if (p < npairs) {
-                L2 a = lp[p];
+                L2 a = plain_load(lp + p);
                 D2 o;
                 o.x = cell_op<OP, FP>(to_f64(a.x), s);
                 o.y = cell_op<OP, FP>(to_f64(a.y), s);
-                op[p] = o;
+                plain_store(o, op + p);
             }
         }
     }
@@ -148,7 +159,13 @@ __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, doubl
 
 template <typename L, int OP, int U, bool NT_ST, bool NT_LD>
 __global__ __launch_bounds__(kBlock) void k_binop_scalar_direct(const L* __restrict__ l, double s,
-                                                                double* __restrict__ out, size_t n) {
+                                                                double* __restrict__ out, size_t n, unsigned head) {
+    if (head) {  // see binop_direct_body
+        if (blockIdx.x == 0 && threadIdx.x < head) out[threadIdx.x] = cell_op<OP, true>(to_f64(l[threadIdx.x]), s);
+        l += head;
+        out += head;
+        n -= head;
+    }
     binop_scalar_tile<L, OP, U, NT_ST, NT_LD>(l, s, out, n >> 1, two_front_tile());
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = cell_op<OP, true>(to_f64(l[n - 1]), s);
 }
@@ -259,8 +276,8 @@ __device__ __forceinline__ void binop_lds_body(const L* __restrict__ l, const R*
 
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
 __global__ __launch_bounds__(kBlock) void k_binop_direct(const L* __restrict__ l, const R* __restrict__ r,
-                                                         double* __restrict__ out, size_t n) {
-    binop_direct_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
+                                                         double* __restrict__ out, size_t n, unsigned head = 0) {
+    binop_direct_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n, head);
 }
 
 template <typename L, typename R, int OP, bool NT_ST, bool NT_LD>
@@ -290,9 +307,10 @@ __device__ __forceinline__ void mask_and_body(const uint8_t* __restrict__ lm, co
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD, bool LDS>
 __global__ __launch_bounds__(kBlock) void k_masked_binop(const L* __restrict__ l, const uint8_t* __restrict__ lm,
                                                          const R* __restrict__ r, const uint8_t* __restrict__ rm,
-                                                         double* __restrict__ out, uint8_t* __restrict__ om, size_t n) {
+                                                         double* __restrict__ out, uint8_t* __restrict__ om, size_t n,
+                                                         unsigned head) {
     if constexpr (LDS) binop_lds_body<L, R, OP, NT_ST, NT_LD>(l, r, out, n);
-    else binop_direct_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n);
+    else binop_direct_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n, head);
     mask_and_body(lm, rm, om, n);
 }
 

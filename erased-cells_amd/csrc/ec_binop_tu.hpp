@@ -27,8 +27,9 @@ static ec_status launch_binop_pair(const void* l, const void* r, size_t n, doubl
         k_binop_lds<L, R, OP, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n);
         return check_launch("binop(lds)");
     }
-    const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
-    k_binop_direct<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n);
+    const unsigned head = peel_head(l, sizeof(L), r, sizeof(R), n);
+    const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
+    k_binop_direct<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n, head);
     return check_launch("binop(direct)");
 }
 
@@ -46,11 +47,12 @@ static ec_status launch_masked_pair(const void* l, const uint8_t* lm, const void
     constexpr bool kCanStage = Staged<L>::value || Staged<R>::value;
     if (kCanStage && tu.binop_variant == 1) {
         const size_t tiles = (n / kLdsWaveCells + kWavesPerBlock - 1) / kWavesPerBlock;
-        k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, true><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
+        k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, true><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n, 0u);
         return check_launch("masked_binop(lds)");
     }
-    const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
-    k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, false><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n);
+    const unsigned head = peel_head(l, sizeof(L), r, sizeof(R), n);
+    const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
+    k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, false><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n, head);
     return check_launch("masked_binop(direct)");
 }
 
@@ -62,8 +64,9 @@ static ec_status launch_scalar(const void* l, double rhs, size_t n, double* out,
         k_binop_scalar_cellwise<L, OP><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, rhs, out, n);
         return check_launch("binop_scalar(cellwise)");
     }
-    const size_t tiles = ((n >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
-    k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rhs, out, n);
+    const unsigned head = peel_head(l, sizeof(L), nullptr, 0, n);
+    const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
+    k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rhs, out, n, head);
     return check_launch("binop_scalar(direct)");
 }
 

@@ -86,8 +86,13 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         fa.dt[k] = static_cast<int8_t>(u);
     }
     if (st == EC_OK) {
+        // peel one leading cell when that puts more of the (now same-typed) 1-/2-byte operands on even indices
+        unsigned c0 = 0, c1 = 0;
+        for (int k = 0; k < 4; ++k)
+            if (!fa.is_sc[k] && fa.alias[k] == k) { c0 += peel_cost(fa.p[k], ecl::size_of(u), 0); c1 += peel_cost(fa.p[k], ecl::size_of(u), 1); }
+        fa.head = (n >= 2 && c1 < c0) ? 1 : 0;
         const size_t per_tile = size_t(kBlock) * kFusedU;
-        const unsigned grid = grid_for(((n >> 1) + per_tile - 1) / per_tile);
+        const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
         switch (o2) {
             case EC_ADD: dispatch_fused<EC_ADD>(fa, u, grid, out, out_mask, n, s); break;
             case EC_SUB: dispatch_fused<EC_SUB>(fa, u, grid, out, out_mask, n, s); break;

@@ -33,6 +33,8 @@ struct FusedArgs {
     int8_t o1, o2, o3;
     int8_t nmask;            // number of distinct masks to AND (0 = unmasked call)
     int8_t is_sc[4];         // operand k is a scalar constant (no stream): value sc[k]
+    uint8_t head;            // leading cells (0/1) computed singly so the pair loads of 1-/2-byte cells start on
+                             // even cell indices (peel_head, ec_runtime.hpp); vector kernel only
     double sc[4];
 };
 
@@ -108,16 +110,17 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
 template <typename T, int O1, int O2, int O3>
 __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
     using T2 = vec<T, 2>;
-    const size_t npairs = n >> 1;
+    const unsigned head = fa.head;
+    const size_t npairs = (n - head) >> 1;
     constexpr size_t TILE = size_t(kBlock) * kFusedU;
     const size_t tile = two_front_tile();
     const size_t base = tile * TILE + threadIdx.x;
     constexpr bool has_w = O3 != kOpNone;
-    D2* __restrict__ op = reinterpret_cast<D2*>(out);
-    const T2* __restrict__ px = static_cast<const T2*>(fa.p[0]);
-    const T2* __restrict__ py = static_cast<const T2*>(fa.p[1]);
-    const T2* __restrict__ pz = static_cast<const T2*>(fa.p[2]);
-    const T2* __restrict__ pw = static_cast<const T2*>(fa.p[3]);
+    D2* __restrict__ op = reinterpret_cast<D2*>(out + head);
+    const T2* __restrict__ px = reinterpret_cast<const T2*>(static_cast<const T*>(fa.p[0]) + head);
+    const T2* __restrict__ py = reinterpret_cast<const T2*>(static_cast<const T*>(fa.p[1]) + head);
+    const T2* __restrict__ pz = reinterpret_cast<const T2*>(static_cast<const T*>(fa.p[2]) + head);
+    const T2* __restrict__ pw = reinterpret_cast<const T2*>(static_cast<const T*>(fa.p[3]) + head);
     // launch-uniform operand configuration, resolved once per wave
     const bool ld_x = !fa.is_sc[0], ld_y = !fa.is_sc[1] && fa.alias[1] == 1, ld_z = !fa.is_sc[2] && fa.alias[2] == 2,
                ld_w = has_w && !fa.is_sc[3] && fa.alias[3] == 3;
@@ -150,10 +153,12 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
             nt_store(o, op + pr);
         }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const size_t i = n - 1;
-        out[i] = fused_cell_t<O1, O2, O3>(operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
-                                          has_w ? operand_cell(fa, 3, i) : 0.0);
+    if (blockIdx.x == 0 && threadIdx.x < 2) {  // the peeled head cell (lane 0) and the odd tail cell (lane 1)
+        const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;
+        const size_t i = threadIdx.x == 0 ? 0 : n - 1;
+        if (do_it)
+            out[i] = fused_cell_t<O1, O2, O3>(operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
+                                              has_w ? operand_cell(fa, 3, i) : 0.0);
     }
     fused_mask_phase(fa, out_mask, n);
 }
