@@ -58,9 +58,13 @@ def main():
         mm, mmo = m.shard(off, n), mo.shard(off, n)
         import ctypes as C
         mn, mx = ec._ffi.EcValue(), ec._ffi.EcValue()
+        nd16 = ec.CellValue(ec.UInt16, 0).to_ec()
         return [
             ("binop Div UInt8/UInt16", 11, lambda: chk(L.ec_binop(ec.DIV, ec.UInt8, l.mem.ptr, ec.UInt16, r.mem.ptr, n, o.mem.ptr, stream))),
             ("convert Float32->Float64", 12, lambda: chk(L.ec_convert(ec.Float32, f.mem.ptr, ec.Float64, o.mem.ptr, n, stream))),
+            ("convert UInt16->Float32", 6, lambda: chk(L.ec_convert(ec.UInt16, r.mem.ptr, ec.Float32, o.mem.ptr, n, stream))),
+            ("convert UInt8->Float64", 9, lambda: chk(L.ec_convert(ec.UInt8, l.mem.ptr, ec.Float64, o.mem.ptr, n, stream))),
+            ("mask_from_nodata UInt16", 3, lambda: chk(L.ec_mask_from_nodata(ec.UInt16, r.mem.ptr, n, C.byref(nd16), mmo.mem.ptr, stream))),
             ("mask_not", 2, lambda: chk(L.ec_mask_not(mm.mem.ptr, n, mmo.mem.ptr, stream))),
             ("min_max UInt16", 2, lambda: chk(L.ec_min_max(ec.UInt16, r.mem.ptr, None, n, C.byref(mn), C.byref(mx), stream))),
             ("fused NDVI UInt16", 12, lambda: ec.fused.ndvi(r, r.shard(0, n))),
