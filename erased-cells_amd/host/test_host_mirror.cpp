@@ -429,7 +429,18 @@ static void gdal_tests(const std::string& data_dir) {
     CHECK_THROWS(Error, RasterBand::open(path("does-not-exist.tiff")));
 }
 
-static void debug_format_checks() {  // Rust `{:?}` of floats; no device needed
+// examples/macros.rs: the `with_ct!` type table stamps out a match over every cell type
+static const char* primitive_name(CellType ct) {
+    switch (ct) {
+#define EC_NAME(ID, P) case CellType::ID: return #P;
+        EC_HOST_WITH_CT(EC_NAME)
+#undef EC_NAME
+    }
+    return "?";
+}
+
+static void debug_format_checks() {
+    CHECK(std::string(primitive_name(CellType::Float32)) == "float" && std::string(primitive_name(CellType::UInt16)) == "uint16_t");  // Rust `{:?}` of floats; no device needed
     CHECK(rust_debug(0.25) == "0.25" && rust_debug(37.0) == "37.0" && rust_debug(-0.0) == "-0.0");
     CHECK(rust_debug(1e-7) == "1e-7" && rust_debug(1e16) == "1e16" && rust_debug(1.5e300) == "1.5e300");
     CHECK(rust_debug(123456789012345680.0) == "1.2345678901234568e17" && rust_debug(0.0001) == "0.0001" && rust_debug(0.00001) == "1e-5");
