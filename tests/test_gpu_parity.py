@@ -6,6 +6,8 @@ The only tolerance: a NaN whose sign/payload the reference itself does not pin â
 both operands NaN in a commutative op, where the x86 result depends on which
 operand the compiler put first â€” is compared by class.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -386,7 +388,7 @@ def test_randomised_shapes_types_and_windows(ec, ua):
     mpool = rand_mask(70000, 950)
     dmask = ec.Mask.new(mpool)
 
-    @settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=int(os.environ.get("EC_PROP_EXAMPLES", "300")), deadline=None, suppress_health_check=list(HealthCheck))
     @given(lt=st.integers(0, NT - 1), rt=st.integers(0, NT - 1), op=st.integers(0, 3),
            n=st.one_of(st.integers(0, 40), st.integers(500, 1100), st.integers(4000, 4200), st.integers(60000, 65000)),
            lo=st.sampled_from([0, 1, 2, 3, 5, 8, 16, 17, 32, 48, 64, 1000]),
