@@ -102,9 +102,8 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
 // loop-free form runs ≈5 % faster than a grid capped at a few blocks per CU).  The grid must be
 // exactly ceil(npairs / TILE) workgroups (two_front_tile is a permutation of the tile indices).
 // `head` (0 or 1, chosen by the launcher: peel_head() in ec_runtime.hpp) leading cells are computed one by
-// one by workgroup 0 and the pair grid starts after them, so that the 2-cell loads of 1- and 2-byte operands
-// fall on even cell indices: a u8x2 load at an odd address or a u16x2 load at 2 mod 4 runs ≈8 % slower
-// (profiles/r01/unaligned_windows.md), while the f64 pair store does not mind being 8 bytes off.
+// one by workgroup 0 and the pair grid starts after them, so that the 2-cell loads of 1-byte operands fall on
+// even addresses (measurements and the rule: ec_runtime.hpp).
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const R* __restrict__ r,
                                                   double* __restrict__ out, size_t n, unsigned head) {

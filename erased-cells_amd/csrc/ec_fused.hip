@@ -86,11 +86,11 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         fa.dt[k] = static_cast<int8_t>(u);
     }
     if (st == EC_OK) {
-        // peel one leading cell when that puts more of the (now same-typed) 1-/2-byte operands on even indices
+        // peel one leading cell when that puts more of the (now same-typed) 1-byte operands on even addresses
         unsigned c0 = 0, c1 = 0;
         for (int k = 0; k < 4; ++k)
             if (!fa.is_sc[k] && fa.alias[k] == k) { c0 += peel_cost(fa.p[k], ecl::size_of(u), 0); c1 += peel_cost(fa.p[k], ecl::size_of(u), 1); }
-        fa.head = (n >= 2 && c1 < c0) ? 1 : 0;
+        fa.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
         const size_t per_tile = size_t(kBlock) * kFusedU;
         const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
         switch (o2) {

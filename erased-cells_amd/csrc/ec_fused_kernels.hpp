@@ -33,8 +33,8 @@ struct FusedArgs {
     int8_t o1, o2, o3;
     int8_t nmask;            // number of distinct masks to AND (0 = unmasked call)
     int8_t is_sc[4];         // operand k is a scalar constant (no stream): value sc[k]
-    uint8_t head;            // leading cells (0/1) computed singly so the pair loads of 1-/2-byte cells start on
-                             // even cell indices (peel_head, ec_runtime.hpp); vector kernel only
+    uint8_t head;            // leading cells (0/1) computed singly so the pair loads of 1-byte cells start on even
+                             // addresses (peel_head, ec_runtime.hpp); vector kernel only
     double sc[4];
 };
 

@@ -30,6 +30,7 @@ struct Tuning {
     int binop_variant = 0;  // 0 = direct narrow loads, 1 = LDS-staged narrow operands
     int reduce_bpc = 8;     // blocks per CU for reductions (partials are per block)
     int map_u = 2;          // 16-B groups per lane per tile for the map kernels (1, 2 or 4)
+    int peel = 1;              // leading-cell peel of the binop/fused kernels: 0 off, 1 for 1-byte operands, 2 also for 2-byte ones
     int unaligned_vector = 1;  // 1 = vector kernels at any cell offset (gfx950 unaligned global access);
                                // 0 = pointers that are not 16-byte aligned run the cell-wise kernels
 };
@@ -53,14 +54,17 @@ inline bool aligned_to(const void* a, size_t bytes) {
     return tuning().unaligned_vector || reinterpret_cast<uintptr_t>(a) % bytes == 0;
 }
 
-// Leading cells (0 or 1) the direct binop kernels peel so that the 2-cell loads of 1- and 2-byte operands
-// start on even cell indices (sub-dword-misaligned pair loads run ≈8 % slower; 4- and 8-byte cells are
-// dword-aligned at any index).  When the two operands disagree, the wider one is served.
+// Leading cells (0 or 1) the direct binop / fused kernels peel so that the 2-cell loads of 1-byte operands start
+// on even addresses: a u8x2 load at an odd address costs ≈6 % of the kernel, more than the 8-byte shift of the
+// f64 pair stores the peel causes (u8∘u16 at an odd offset: 0.75 of peak unpeeled, 0.78–0.80 peeled).  Pair
+// loads of 2-byte cells at 2 mod 4 cost nothing, so they are left alone — peeling for them only misaligns the
+// output (u16∘u16: 0.78 unpeeled, 0.70–0.73 peeled; profiles/r01/peel_ab.md).
 inline unsigned peel_cost(const void* p, size_t size, unsigned h) {
-    return size < 4 ? static_cast<unsigned>(size) * static_cast<unsigned>(((reinterpret_cast<uintptr_t>(p) / size) + h) & 1) : 0u;
+    const bool counts = size == 1 || (size == 2 && tuning().peel >= 2);
+    return counts ? static_cast<unsigned>(size) * static_cast<unsigned>(((reinterpret_cast<uintptr_t>(p) / size) + h) & 1) : 0u;
 }
 inline unsigned peel_head(const void* l, size_t lsize, const void* r, size_t rsize, size_t n) {
-    if (n < 2) return 0;
+    if (n < 2 || !tuning().peel) return 0;
     const unsigned c0 = peel_cost(l, lsize, 0) + (r ? peel_cost(r, rsize, 0) : 0);
     const unsigned c1 = peel_cost(l, lsize, 1) + (r ? peel_cost(r, rsize, 1) : 0);
     return c1 < c0 ? 1u : 0u;

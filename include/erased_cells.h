@@ -240,7 +240,8 @@ ec_status ec_synth_mask(uint8_t *dst, size_t n, uint64_t seed, uint64_t base, ui
 /* Tuning knobs: "binop_variant" (0 direct narrow loads, 1 LDS-staged), "reduce_bpc" (workgroups per CU for reductions),
  * "map_u" (16-B groups per lane per tile of the map kernels: 1, 2 or 4), "unaligned_vector" (1, default: vector
  * kernels at any cell offset via unaligned global access; 0: pointers that are not 16-byte aligned run the
- * one-cell-per-lane kernels). */
+ * one-cell-per-lane kernels), "peel" (leading-cell peel of the binop/fused kernels at odd offsets: 0 off, 1 for
+ * 1-byte operands (default), 2 also for 2-byte operands). */
 ec_status ec_tune_set(const char *key, int64_t value);
 
 #ifdef __cplusplus

@@ -61,6 +61,7 @@ def main():
         nd16 = ec.CellValue(ec.UInt16, 0).to_ec()
         return [
             ("binop Div UInt8/UInt16", 11, lambda: chk(L.ec_binop(ec.DIV, ec.UInt8, l.mem.ptr, ec.UInt16, r.mem.ptr, n, o.mem.ptr, stream))),
+            ("binop Add UInt8+UInt16", 11, lambda: chk(L.ec_binop(ec.ADD, ec.UInt8, l.mem.ptr, ec.UInt16, r.mem.ptr, n, o.mem.ptr, stream))),
             ("convert Float32->Float64", 12, lambda: chk(L.ec_convert(ec.Float32, f.mem.ptr, ec.Float64, o.mem.ptr, n, stream))),
             ("convert UInt16->Float32", 6, lambda: chk(L.ec_convert(ec.UInt16, r.mem.ptr, ec.Float32, o.mem.ptr, n, stream))),
             ("convert UInt8->Float64", 9, lambda: chk(L.ec_convert(ec.UInt8, l.mem.ptr, ec.Float64, o.mem.ptr, n, stream))),
