@@ -27,13 +27,17 @@ def ec():
     return ec
 
 
-@pytest.fixture(params=[1, 0], ids=["vector-any-offset", "cellwise-when-unaligned"])
+@pytest.fixture(params=[(1, 1), (0, 1), (1, 2), (1, 0)],
+                ids=["default", "cellwise-when-unaligned", "peel-2-byte-operands-too", "no-peel"])
 def ua(ec, request):
-    """Windows that are not 16-byte aligned: vector kernels with unaligned global access (default) or,
-    with the knob off, the cell-wise kernels.  Both must match the oracle."""
-    ec.lib().ec_tune_set(b"unaligned_vector", request.param)
+    """Alternative paths for windows that are not 16-byte aligned; all must match the oracle.
+    unaligned_vector: vector kernels with unaligned global access (default) or, knob off, the cell-wise kernels.
+    peel: leading-cell peel of the binop/fused kernels for 1-byte operands (default), also 2-byte ones, or never."""
+    ec.lib().ec_tune_set(b"unaligned_vector", request.param[0])
+    ec.lib().ec_tune_set(b"peel", request.param[1])
     yield request.param
     ec.lib().ec_tune_set(b"unaligned_vector", 1)
+    ec.lib().ec_tune_set(b"peel", 1)
 
 
 def _both_nan(l, r):
