@@ -473,6 +473,46 @@ def test_randomised_shapes_types_and_windows(ec, ua):
         ec.lib().ec_tune_set(b"binop_variant", 0)
 
 
+@pytest.mark.parametrize("map_u,reduce_bpc", [(1, 1), (4, 16), (2, 3)])
+def test_tuning_knobs_do_not_change_results(ec, map_u, reduce_bpc):
+    """The non-default launch shapes behind ec_tune_set("map_u" / "reduce_bpc") are separate kernel instantiations
+    and grid sizes; every map kernel and reduction must give the oracle's bits with them too."""
+    L = ec.lib()
+    L.ec_tune_set(b"map_u", map_u)
+    L.ec_tune_set(b"reduce_bpc", reduce_bpc)
+    try:
+        n = 300001
+        m1, m2 = rand_mask(n, 71), rand_mask(n, 72)
+        dm1, dm2 = ec.Mask.new(m1), ec.Mask.new(m2)
+        assert np.array_equal((dm1 & dm2).to_numpy(), eco.mask_and(m1, m2))
+        assert np.array_equal((dm1 | dm2).to_numpy(), eco.mask_or(m1, m2))
+        assert np.array_equal((~dm1).to_numpy(), eco.mask_not(m1))
+        assert dm1.counts() == eco.mask_counts(m1)
+        for ct in range(NT):
+            a = rand_cells(ct, n, 700 + ct)
+            d = ec.CellBuffer.from_vec(a)
+            assert np.array_equal(bits_of((-d).to_numpy()), bits_of(eco.f_neg(a)))
+            for dst in (eco.F64, eco.union(ct, eco.I16)):
+                if eco.can_fit_into(ct, dst) and dst != ct:
+                    assert np.array_equal(bits_of(d.convert(dst).to_numpy()), bits_of(eco.f_convert(a, dst)))
+            for mask, dmask in ((None, None), (m1, dm1)):
+                got = (d.min_max() if mask is None else ec.MaskedCellBuffer(d, dmask).min_max())
+                exp = eco.f_min_max(a, mask)
+                assert (got[0].bits(), got[1].bits()) == (exp[0].bits(), exp[1].bits())
+            nd = eco.nodata_value(eco.ND_DEFAULT, ct)
+            assert np.array_equal(ec.mask_from_nodata(d, ec.NoData.default()).to_numpy(), eco.f_mask_from_nodata(a, nd))
+            sel = ec.MaskedCellBuffer(d, dm2).to_vec_with_nodata(ct, ec.NoData.default())
+            assert np.array_equal(bits_of(sel), bits_of(eco.f_mask_select(a, m2, nd)))
+            b = a.copy()
+            b[n - 7] = a[0]
+            assert d.cmp(ec.CellBuffer.from_vec(b)) == eco.buffer_cmp(a, b)
+            f = ec.CellBuffer.fill(n, ec.CellValue(ct, a[3]))
+            assert np.array_equal(bits_of(f.to_numpy()), bits_of(np.full(n, a[3], dtype=a.dtype)))
+    finally:
+        L.ec_tune_set(b"map_u", 2)
+        L.ec_tune_set(b"reduce_bpc", 8)
+
+
 def test_streams_threads_and_graph_capture(ec):
     """Re-entrancy: concurrent host threads on distinct streams (per-stream reduction scratch, per-thread
     device binding), and a chain of asynchronous calls captured into a hipGraph and replayed."""
