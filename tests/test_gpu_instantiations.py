@@ -1,0 +1,163 @@
+"""Every kernel instantiation the library ships is executed at least once against the oracle.
+
+The parity tests walk the default path over all type pairs; this file sweeps the remaining template
+instantiations — the LDS-staged variant, the masked kernels, all 800 fused (type x op-triple) kernels, the
+map kernels at every tile depth and the cell-wise comparison path — on small inputs.  (Which kernels a run
+executed can be listed with `rocprofv3 --kernel-trace --stats -- python3 -m pytest tests -m gpu`.)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import eco
+from vectors import assert_f64_bits_equal, bits_of, rand_cells, rand_mask
+
+pytestmark = pytest.mark.gpu
+
+OPS = [eco.ADD, eco.SUB, eco.MUL, eco.DIV]
+NT = eco.NTYPES
+N = 2600  # a few wave tiles + a ragged tail
+
+
+@pytest.fixture(scope="module")
+def ec():
+    import erased_cells_hip as ec
+    ec.init(0)
+    return ec
+
+
+@pytest.fixture(scope="module")
+def pool(ec):
+    host = {ct: rand_cells(ct, N + 8, 4100 + ct) for ct in range(NT)}
+    dev = {ct: ec.CellBuffer.from_vec(a) for ct, a in host.items()}
+    m = [rand_mask(N + 8, 4200 + k) for k in range(2)]
+    return host, dev, m, [ec.Mask.new(x) for x in m]
+
+
+def _both_nan(l, r):
+    with np.errstate(all="ignore"):
+        return np.isnan(l.astype(np.float64)) & np.isnan(r.astype(np.float64))
+
+
+def _loose(op, l, r):
+    return _both_nan(l, r) if op in (eco.ADD, eco.MUL) else None
+
+
+@pytest.mark.parametrize("variant,vector,off", [(1, 1, 0), (0, 0, 1)], ids=["lds-staged", "cellwise"])
+def test_binop_and_masked_binop_every_pair(ec, pool, variant, vector, off):
+    """k_binop_lds / k_masked_binop<LDS> for every staged pair, and the cell-wise kernels for every pair
+    (windows one cell into the buffers with the vector path switched off)."""
+    host, dev, m, dm = pool
+    L = ec.lib()
+    L.ec_tune_set(b"binop_variant", variant)
+    L.ec_tune_set(b"unaligned_vector", vector)
+    try:
+        for lt in range(NT):
+            for rt in range(NT):
+                l, r = host[lt][off:off + N], host[rt][off:off + N]
+                dl, dr = dev[lt].shard(off, N), dev[rt].shard(off, N)
+                ml = ec.MaskedCellBuffer(dl, dm[0].shard(off, N))
+                mr = ec.MaskedCellBuffer(dr, dm[1].shard(off, N))
+                for op in OPS:
+                    exp = eco.f_binop(op, l, r)
+                    assert_f64_bits_equal(dl._binop(op, dr).to_numpy(), exp, nan_by_class_where=_loose(op, l, r))
+                    got = ml._binop(op, mr)
+                    assert_f64_bits_equal(got.buffer().to_numpy(), exp, nan_by_class_where=_loose(op, l, r))
+                    assert np.array_equal(got.mask().to_numpy(), m[0][off:off + N] & m[1][off:off + N])
+            if vector == 0:  # scalar cell-wise kernels
+                for op in OPS:
+                    got = dev[lt].shard(off, N)._binop(op, 3)
+                    assert_f64_bits_equal(got.to_numpy(), eco.f_binop_scalar(op, host[lt][off:off + N], eco.Value.of(eco.I32, 3)))
+    finally:
+        L.ec_tune_set(b"binop_variant", 0)
+        L.ec_tune_set(b"unaligned_vector", 1)
+
+
+def test_masked_binop_direct_every_pair(ec, pool):
+    host, dev, m, dm = pool
+    for lt in range(NT):
+        ml = ec.MaskedCellBuffer(dev[lt].shard(0, N), dm[0].shard(0, N))
+        for rt in range(NT):
+            mr = ec.MaskedCellBuffer(dev[rt].shard(0, N), dm[1].shard(0, N))
+            l, r = host[lt][:N], host[rt][:N]
+            for op in OPS:
+                got = ml._binop(op, mr)
+                assert_f64_bits_equal(got.buffer().to_numpy(), eco.f_binop(op, l, r), nan_by_class_where=_loose(op, l, r))
+                assert np.array_equal(got.mask().to_numpy(), m[0][:N] & m[1][:N])
+
+
+@pytest.mark.parametrize("ct", range(NT))
+def test_fused_every_op_triple(ec, pool, ct):
+    """All 80 (o1, o2, o3) instantiations of k_fused_same<T> for each cell type: bit-identical to the eager chain."""
+    host, dev, _, _ = pool
+    x, y = dev[ct].shard(0, N), dev[ct].shard(4, N)
+    for o1 in OPS:
+        t1 = x._binop(o1, y)
+        for o2 in OPS:
+            for o3 in OPS + [ec.fused.OP_NONE]:
+                if o3 == ec.fused.OP_NONE:
+                    got = ec.fused.expr(x, o1, y, o2, y)
+                    exp = t1._binop(o2, y)
+                else:
+                    got = ec.fused.expr(x, o1, y, o2, y, o3, x)
+                    exp = t1._binop(o2, y._binop(o3, x))
+                assert np.array_equal(bits_of(got.to_numpy()), bits_of(exp.to_numpy())), (ct, o1, o2, o3)
+
+
+@pytest.mark.parametrize("map_u,vector,off", [(1, 1, 0), (2, 1, 0), (4, 1, 0), (2, 0, 1)],
+                         ids=["tile-depth-1", "tile-depth-2", "tile-depth-4", "cellwise"])
+def test_map_kernels_every_instantiation(ec, pool, map_u, vector, off):
+    """convert (every legal pair), neg, fill, mask_from_nodata, mask_select, mask logic and the reductions at every
+    tile depth of k_map, and through the cell-wise kernels."""
+    host, dev, m, dm = pool
+    L = ec.lib()
+    L.ec_tune_set(b"map_u", map_u)
+    L.ec_tune_set(b"unaligned_vector", vector)
+    try:
+        ma, mb = dm[0].shard(off, N), dm[1].shard(off, N)
+        ha, hb = m[0][off:off + N], m[1][off:off + N]
+        assert np.array_equal((ma & mb).to_numpy(), eco.mask_and(ha, hb))
+        assert np.array_equal((ma | mb).to_numpy(), eco.mask_or(ha, hb))
+        assert np.array_equal((~ma).to_numpy(), eco.mask_not(ha))
+        assert ma.counts() == eco.mask_counts(ha)
+        for ct in range(NT):
+            a, d = host[ct][off:off + N], dev[ct].shard(off, N)
+            for dst in range(NT):
+                if dst != ct and eco.can_fit_into(ct, dst):
+                    assert np.array_equal(bits_of(d.convert(dst).to_numpy()), bits_of(eco.f_convert(a, dst))), (ct, dst)
+            assert np.array_equal(bits_of((-d).to_numpy()), bits_of(eco.f_neg(a)))
+            nd = eco.nodata_value(eco.ND_DEFAULT, ct)
+            assert np.array_equal(ec.mask_from_nodata(d, ec.NoData.default()).to_numpy(), eco.f_mask_from_nodata(a, nd))
+            sel = ec.MaskedCellBuffer(d, mb).to_vec_with_nodata(ct, ec.NoData.default())
+            assert np.array_equal(bits_of(sel), bits_of(eco.f_mask_select(a, hb, nd)))
+            for mask, dmask in ((None, None), (ha, ma)):
+                got = d.min_max() if mask is None else ec.MaskedCellBuffer(d, dmask).min_max()
+                exp = eco.f_min_max(a, mask)
+                assert (got[0].bits(), got[1].bits()) == (exp[0].bits(), exp[1].bits())
+            b = a.copy()
+            b[N - 3] = a[1]
+            assert d.cmp(ec.CellBuffer.from_vec(b)) == eco.buffer_cmp(a, b)
+            f = ec.CellBuffer.fill(N, ec.CellValue(ct, a[5]))
+            assert np.array_equal(bits_of(f.to_numpy()), bits_of(np.full(N, a[5], dtype=a.dtype)))
+            w = ec.CellBuffer.empty(N + 8, ct).shard(off, N)  # fill into a window (the cell-wise fill when off = 1)
+            v = ec.CellValue(ct, a[6]).to_ec()
+            ec._ffi.check(L.ec_fill(ct, w.mem.ptr, N, C.byref(v), None))
+            assert np.array_equal(bits_of(w.to_numpy()), bits_of(np.full(N, a[6], dtype=a.dtype)))
+        # the device-side input generators of bench.py / the tests (test support)
+        h = np.array([eco.splitmix64(0xABCD ^ (11 + i)) for i in range(N)], dtype=np.uint64)
+        for ct, lo, hi in ((ec.UInt8, 3, 250), (ec.UInt16, 1, 65535), (ec.UInt32, 7, 4000000000)):
+            w = ec.CellBuffer.empty(N + 8, ct).shard(off, N)
+            ec._ffi.check(L.ec_synth_fill(ct, w.mem.ptr, N, 0xABCD, 11, float(lo), float(hi), None))
+            assert np.array_equal(w.to_numpy(), (np.uint64(lo) + h % np.uint64(hi - lo + 1)).astype(ec.NP_DTYPES[ct]))
+        unit = (h >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+        for ct in (ec.Float32, ec.Float64):
+            w = ec.CellBuffer.empty(N + 8, ct).shard(off, N)
+            ec._ffi.check(L.ec_synth_fill(ct, w.mem.ptr, N, 0xABCD, 11, -1000.0, 1000.0, None))
+            assert np.array_equal(bits_of(w.to_numpy()), bits_of((-1000.0 + 2000.0 * unit).astype(ec.NP_DTYPES[ct])))
+        wm = ec.Mask.empty(N + 8).shard(off, N)
+        ec._ffi.check(L.ec_synth_mask(wm.mem.ptr, N, 0xABCD, 11, 30, None))
+        assert np.array_equal(wm.to_numpy(), (h % np.uint64(100) >= np.uint64(30)).astype(np.uint8))
+    finally:
+        L.ec_tune_set(b"map_u", 2)
+        L.ec_tune_set(b"unaligned_vector", 1)
