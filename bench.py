@@ -12,6 +12,10 @@ fixed at 16384² (north_star) and each rank owns rows/N of it.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
+Timing: W warm-up steps, barrier + synchronize, K launches, synchronize, barrier.  Each rank's clock runs
+from the opening barrier to its own closing synchronize (its K steps complete on the device); the MAX over
+ranks is reported, so the closing barrier's own latency is outside the figure and a straggler is inside it.
+
 Rank 0 prints ONE JSON line: BASELINE.json's metric (Gcells/s, whole job), a
 `roofline` object for the dominant kernel (HIP-event timed, algorithmic bytes =
 11 B/cell) and, at N=1, a `cpu_baseline` object: the oracle's reference-shaped
@@ -358,8 +362,9 @@ def main():
         for _ in range(args.steps):
             step()
     ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    torch.cuda.synchronize()              # this rank's K steps are complete on the device
+    elapsed = time.perf_counter() - t0    # per-rank time of exactly K steps; the MAX over ranks is reported
+    barrier()                             # closing bracket: every rank is done before anything else happens
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream
 
     tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
