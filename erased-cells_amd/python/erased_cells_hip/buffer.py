@@ -19,7 +19,6 @@ from typing import Callable, Optional, Sequence
 
 import numpy as np
 
-from . import _ffi
 from ._ffi import EcValue, check, lib
 
 # CellType (src/ctype.rs:11-20; order of with_ct!, src/lib.rs:89-98)

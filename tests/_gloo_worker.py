@@ -10,7 +10,6 @@ import json
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import eco
-from oracle.eco import ADD, DIV, F32, F64, MUL, ND_DEFAULT, ND_VALUE, NP_DTYPES, NTYPES, SUB, Value
+from oracle.eco import ADD, DIV, F32, F64, MUL, ND_DEFAULT, ND_VALUE, NTYPES, SUB, Value
 from vectors import assert_f64_bits_equal, bits_of, rand_cells, rand_mask
 
 N = 777  # not a multiple of any vector width
