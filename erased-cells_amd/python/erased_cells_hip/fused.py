@@ -59,3 +59,71 @@ def ndvi(nir, red):
 def add_mul(a, b, c):
     """(a + b) * c, one pass (BASELINE config 3)."""
     return expr(a, B.ADD, b, B.MUL, c)
+
+
+class Lazy:
+    """Operator syntax that defers evaluation, so a chain written the reference's way runs fused:
+
+        n, r = lazy(nir), lazy(red)
+        ndvi = ((n - r) / (n + r)).eval()        # one pass, bit-identical to (nir - red) / (nir + red)
+
+    A tree is evaluated bottom-up; wherever a node's children are at most one operator deep — `(x o1 y) o2 z`,
+    `(x o1 y) o2 (z o3 w)` — that node runs as one fused launch, deeper sub-trees are evaluated first (each
+    again fused as far as it goes).  Leaves are buffers (all plain or all masked) or scalars.
+    The C++ mirror has the same as expression templates (`lazy()`, host/erased_cells.hpp)."""
+
+    __slots__ = ("op", "l", "r", "leaf")
+
+    def __init__(self, leaf=None, op=None, l=None, r=None):
+        self.leaf, self.op, self.l, self.r = leaf, op, l, r
+
+    @staticmethod
+    def _wrap(x) -> "Lazy":
+        return x if isinstance(x, Lazy) else Lazy(leaf=x)
+
+    def _node(self, op, other, swap=False):
+        a, b = (Lazy._wrap(other), self) if swap else (self, Lazy._wrap(other))
+        return Lazy(op=op, l=a, r=b)
+
+    def __add__(self, o): return self._node(B.ADD, o)
+    def __sub__(self, o): return self._node(B.SUB, o)
+    def __mul__(self, o): return self._node(B.MUL, o)
+    def __truediv__(self, o): return self._node(B.DIV, o)
+    def __radd__(self, o): return self._node(B.ADD, o, swap=True)
+    def __rsub__(self, o): return self._node(B.SUB, o, swap=True)
+    def __rmul__(self, o): return self._node(B.MUL, o, swap=True)
+    def __rtruediv__(self, o): return self._node(B.DIV, o, swap=True)
+
+    def _depth(self) -> int:
+        return 0 if self.op is None else 1 + max(self.l._depth(), self.r._depth())
+
+    def _flat(self) -> "Lazy":
+        """This sub-tree as a leaf (evaluating it if it is not one already)."""
+        return self if self.op is None else Lazy(leaf=self.eval())
+
+    def eval(self):
+        if self.op is None:
+            return self.leaf
+        l = self.l if self.l._depth() <= 1 else self.l._flat()
+        r = self.r if self.r._depth() <= 1 else self.r._flat()
+        if l.op is None and r.op is None:           # x o y
+            a, b = l.leaf, r.leaf
+            if _is_buf(a):
+                return a._binop(self.op, b)
+            if _is_buf(b):                            # scalar o buffer: only the buffer-on-the-left form exists eagerly
+                return expr(a, self.op, b, B.MUL, 1.0)  # (s o b) * 1.0 — exact, the product by one is the identity in f64
+            return B.CellValue.new(a)._scalar_op(b, {B.ADD: lambda p, q: p + q, B.SUB: lambda p, q: p - q,
+                                                      B.MUL: lambda p, q: p * q, B.DIV: lambda p, q: p / q}[self.op])
+        if l.op is not None and r.op is None:        # (x o1 y) o2 z
+            if _is_buf(l.l.leaf) or _is_buf(l.r.leaf) or _is_buf(r.leaf):
+                return expr(l.l.leaf, l.op, l.r.leaf, self.op, r.leaf)
+        if l.op is not None and r.op is not None:    # (x o1 y) o2 (z o3 w)
+            leaves = (l.l.leaf, l.r.leaf, r.l.leaf, r.r.leaf)
+            if any(_is_buf(x) for x in leaves):
+                return expr(leaves[0], l.op, leaves[1], self.op, leaves[2], r.op, leaves[3])
+        # z o2 (x o1 y), or sub-trees without buffers: evaluate the children, then one plain op
+        return Lazy(op=self.op, l=l._flat(), r=r._flat()).eval()
+
+
+def lazy(x) -> Lazy:
+    return Lazy(leaf=x)

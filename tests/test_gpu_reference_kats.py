@@ -79,6 +79,31 @@ def test_buffer_and_masked_extend(ec):
     assert e.to_numpy().tolist() == [1.5, 2.0] and e.cell_type() == ec.Float32
 
 
+def test_lazy_operator_syntax_runs_fused_and_matches_eager(ec):
+    """`lazy()` defers the reference's operator chains (src/gdal/rasterband.rs:148, examples/masked.rs:12) so that they
+    run as fused launches; every tree shape gives the eager chain's bits."""
+    lz = ec.fused.lazy
+    a = ec.CellBuffer.from_vec(rand_cells(ec.UInt16, 5000, 11))
+    b = ec.CellBuffer.from_vec(rand_cells(ec.UInt16, 5000, 12))
+    c = ec.CellBuffer.from_vec(rand_cells(ec.Float32, 5000, 13))
+    same = lambda x, y: x.cell_type() == y.cell_type() and np.array_equal(bits_of(x.to_numpy()), bits_of(y.to_numpy()))
+    A, Bz, Cz = lz(a), lz(b), lz(c)
+    assert same(((A - Bz) / (A + Bz)).eval(), (a - b) / (a + b))               # (x o1 y) o2 (z o3 w)
+    assert same(((A + Bz) * 2.0).eval(), (a + b) * 2.0)                          # (x o1 y) o2 scalar
+    assert same(((A + Bz) * Cz).eval(), (a + b) * c)                             # mixed cell types
+    assert same((A / Bz).eval(), a / b)                                          # a single op stays a single op
+    assert same((Cz * ((A - Bz) / (A + Bz)) + 1).eval(), c * ((a - b) / (a + b)) + 1)    # deeper: sub-trees first
+    assert same((Cz / (A + Bz)).eval(), c / (a + b))                             # node on the right only
+    assert same((2.0 * A).eval(), a * 2.0)                                       # scalar on the left
+    one_minus = (1 - A).eval().to_numpy()
+    assert np.array_equal(bits_of(one_minus), bits_of(1.0 - a.to_numpy().astype(np.float64)))
+    ma = ec.MaskedCellBuffer.from_vec_with_nodata(rand_cells(ec.UInt16, 5000, 14), ec.NoData.new(0))
+    mb = ec.MaskedCellBuffer.from_vec(rand_cells(ec.UInt16, 5000, 15))
+    got, exp = ((lz(ma) + lz(mb)) * 2.0).eval(), (ma + mb) * 2.0
+    assert same(got.buffer(), exp.buffer()) and got.mask() == exp.mask()
+    assert (lz(3) + 4).eval() == ec.CellValue(ec.Float64, 7.0)
+
+
 def test_from_others_and_iterators(ec):
     """src/buffer.rs:528-555 (from_others), src/masked/masked_buffer.rs:457-462 (from_iter), the IntoIterator impls."""
     b = ec.CellBuffer.from_values([ec.CellValue(ec.UInt16, x) for x in (3, 4, 5)])
