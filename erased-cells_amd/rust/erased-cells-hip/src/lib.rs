@@ -13,6 +13,7 @@ pub mod ffi;
 mod cell_value;
 mod device_buffer;
 mod device_mask;
+pub mod fused;
 mod masked;
 pub mod sharded;
 
