@@ -16,8 +16,12 @@ pub enum Operand<'a> {
 impl<'a> From<&'a CellBuffer> for Operand<'a> {
     fn from(b: &'a CellBuffer) -> Self { Operand::Buffer(b) }
 }
-impl<'a, T: Into<CellValue>> From<T> for Operand<'a> {
-    fn from(v: T) -> Self { Operand::Scalar(v.into()) }
+impl<'a> From<CellValue> for Operand<'a> {
+    fn from(v: CellValue) -> Self { Operand::Scalar(v) }
+}
+impl<'a> Operand<'a> {
+    /// `Operand::scalar(2.0)`, `Operand::scalar(3u8)` — any primitive a cell can hold.
+    pub fn scalar<T: Into<CellValue>>(v: T) -> Self { Operand::Scalar(v.into()) }
 }
 
 /// `(x o1 y) o2 z` when `tail` is `None`, `(x o1 y) o2 (z o3 w)` when it is `Some((o3, w))`.
