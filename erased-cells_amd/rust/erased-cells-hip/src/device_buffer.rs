@@ -139,6 +139,11 @@ macro_rules! cb_bin_op {
             type Output = CellBuffer;
             fn $mth(self, rhs: Self) -> CellBuffer { (&self).binop($op, &rhs) }
         }
+        // RHS borrow (src/buffer.rs:338-343)
+        impl $trt<&CellBuffer> for CellBuffer {
+            type Output = CellBuffer;
+            fn $mth(self, rhs: &CellBuffer) -> CellBuffer { (&self).binop($op, rhs) }
+        }
         // RHS scalar (src/buffer.rs:346-352)
         impl<R: Into<CellValue>> $trt<R> for CellBuffer {
             type Output = CellBuffer;
