@@ -156,6 +156,41 @@ __global__ __launch_bounds__(256) void k_lds2(const uint8_t* __restrict__ l, con
     }
 }
 
+// "lds3": as lds2, but the tiles go from global memory straight into the wave-private LDS slab with gfx950's
+// `global_load_lds_dword` (no VGPR round trip, no ds_write): LDS address = M0 base + inst offset + lane*4.
+template <int STPOL, int AUX, int OP, int PERM>
+__global__ __launch_bounds__(256) void k_lds3(const uint8_t* __restrict__ l, const uint16_t* __restrict__ r,
+                                              double* __restrict__ out, size_t n) {
+    __shared__ __attribute__((aligned(16))) unsigned char slab_a[4][256];
+    __shared__ __attribute__((aligned(16))) unsigned char slab_b[4][512];
+    size_t blk = blockIdx.x;
+    if constexpr (PERM == 2) blk = (blockIdx.x & 1) ? gridDim.x - 1 - (blockIdx.x >> 1) : (blockIdx.x >> 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t cell0 = (blk * 4 + wave) * 256;  // host guarantees n % 1024 == 0
+    if (cell0 + 256 > n) return;
+    typedef const void __attribute__((address_space(1)))* gptr;
+    typedef void __attribute__((address_space(3)))* lptr;
+    __builtin_amdgcn_global_load_lds((gptr)(l + cell0 + lane * 4), (lptr)slab_a[wave], 4, 0, AUX);
+    __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const unsigned char*>(r + cell0) + lane * 4), (lptr)slab_b[wave], 4, 0, AUX);
+    __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const unsigned char*>(r + cell0) + lane * 4), (lptr)slab_b[wave], 4, 256, AUX);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    using L2 = vec<uint8_t, 2>;
+    using R2 = vec<uint16_t, 2>;
+    D2* op = reinterpret_cast<D2*>(out + cell0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const L2 a = reinterpret_cast<const volatile L2*>(slab_a[wave])[j * 64 + lane];
+        const R2 b = reinterpret_cast<const volatile R2*>(slab_b[wave])[j * 64 + lane];
+        D2 o;
+        o.x = cell_op<OP, false>(to_f64(a.x), to_f64(b.x));
+        o.y = cell_op<OP, false>(to_f64(a.y), to_f64(b.y));
+        store16<STPOL>(op + j * 64 + lane, o);
+    }
+}
+
 __global__ void k_fill(uint8_t* a, uint16_t* b, size_t n) {
     size_t stride = size_t(gridDim.x) * blockDim.x;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -258,6 +293,9 @@ int main(int argc, char** argv) {
     if (n % 1024 == 0) {
         add("lds2 div U2 wave-private slab, dword/dwordx2 loads, perm2", b11, [=]() { k_lds2<1, true, EC_DIV, 2><<<unsigned(n / 1024), 256>>>(a, b, out, n); });
         add("lds2 div U2 wave-private slab, dword/dwordx2 loads, perm0", b11, [=]() { k_lds2<1, true, EC_DIV, 0><<<unsigned(n / 1024), 256>>>(a, b, out, n); });
+        add("lds3 div direct-to-LDS (global_load_lds_dword), perm2", b11, [=]() { k_lds3<1, 0, EC_DIV, 2><<<unsigned(n / 1024), 256>>>(a, b, out, n); });
+        add("lds3 div direct-to-LDS, nt aux=2, perm2", b11, [=]() { k_lds3<1, 2, EC_DIV, 2><<<unsigned(n / 1024), 256>>>(a, b, out, n); });
+        add("lds3 add direct-to-LDS (global_load_lds_dword), perm2", b11, [=]() { k_lds3<1, 0, EC_ADD, 2><<<unsigned(n / 1024), 256>>>(a, b, out, n); });
         add("lds2 add U2 wave-private slab, dword/dwordx2 loads, perm2", b11, [=]() { k_lds2<1, true, EC_ADD, 2><<<unsigned(n / 1024), 256>>>(a, b, out, n); });
     }
     add("LIB k_binop_direct div U2 nt/nt (library kernel, same buffers)", b11, [=]() {
