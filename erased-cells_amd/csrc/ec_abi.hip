@@ -29,6 +29,7 @@ static std::mutex g_mu;
 static bool g_inited = false;
 static int g_device = -1;
 static int g_cus = 256;
+static_assert(kMaxReduceBlocks <= kFinalizeMaxParts, "the finalize kernels read at most kFinalizeMaxParts partials");
 static Tuning g_tuning;
 static std::map<hipStream_t, Scratch> g_scratch;
 
@@ -181,7 +182,7 @@ static ec_status launch_min_max(const void* p, const uint8_t* mask, size_t n, in
         if (st != EC_OK) return st;
     }
     // sentinels (T::MAX, T::MIN): src/buffer.rs:170, finite for floats (src/ctype.rs:158-179)
-    k_min_max_finalize<<<1, kBlock, 0, s>>>(sc.dev, static_cast<int>(grid), order_key<T>(Limits<T>::hi),
+    k_min_max_finalize<<<1, kFinalizeBlock, 0, s>>>(sc.dev, static_cast<int>(grid), order_key<T>(Limits<T>::hi),
                                             order_key<T>(Limits<T>::lo), keys2_dev);
     return check_launch("min_max(finalize)");
 }
@@ -616,7 +617,7 @@ extern "C" ec_status ec_first_difference(ec_dtype t, const void* l, const void* 
         default: st = first_diff_w<uint64_t>(l, r, n, sc, S(stream), &grid); break;
     }
     if (st != EC_OK) return st;
-    k_first_diff_finalize<<<1, kBlock, 0, S(stream)>>>(reinterpret_cast<const uint64_t*>(sc.dev), static_cast<int>(grid),
+    k_first_diff_finalize<<<1, kFinalizeBlock, 0, S(stream)>>>(reinterpret_cast<const uint64_t*>(sc.dev), static_cast<int>(grid),
                                                        reinterpret_cast<uint64_t*>(sc.dev_result()));
     st = check_launch("first_diff(finalize)");
     if (st != EC_OK) return st;
@@ -753,7 +754,7 @@ extern "C" ec_status ec_mask_counts_device(const uint8_t* m, size_t n, uint64_t*
         st = check_launch("mask_counts(partials)");
         if (st != EC_OK) return st;
     }
-    k_mask_count_finalize<<<1, kBlock, 0, S(stream)>>>(reinterpret_cast<const uint64_t*>(sc.dev), static_cast<int>(grid), n, counts2_dev);
+    k_mask_count_finalize<<<1, kFinalizeBlock, 0, S(stream)>>>(reinterpret_cast<const uint64_t*>(sc.dev), static_cast<int>(grid), n, counts2_dev);
     return check_launch("mask_counts(finalize)");
 }
 
