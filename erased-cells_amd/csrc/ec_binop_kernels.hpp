@@ -62,6 +62,7 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
     using R2 = vec<R, 2>;
     using D2 = vec<double, 2>;
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
     constexpr size_t TILE = size_t(kBlock) * U;
     const L2* __restrict__ lp = reinterpret_cast<const L2*>(l);
     const R2* __restrict__ rp = reinterpret_cast<const R2*>(r);
@@ -78,8 +79,8 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             D2 o;
-            o.x = cell_op<OP, FP>(to_f64(a[j].x), to_f64(b[j].x));
-            o.y = cell_op<OP, FP>(to_f64(a[j].y), to_f64(b[j].y));
+            o.x = cell_op<OP, FP, SM>(to_f64(a[j].x), to_f64(b[j].x));
+            o.y = cell_op<OP, FP, SM>(to_f64(a[j].y), to_f64(b[j].y));
             store_vec<NT_ST>(op + base + size_t(j) * kBlock, o);
         }
     } else {
@@ -90,8 +91,8 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
                 L2 a = plain_load(lp + p);
                 R2 b = plain_load(rp + p);
                 D2 o;
-                o.x = cell_op<OP, FP>(to_f64(a.x), to_f64(b.x));
-                o.y = cell_op<OP, FP>(to_f64(a.y), to_f64(b.y));
+                o.x = cell_op<OP, FP, SM>(to_f64(a.x), to_f64(b.x));
+                o.y = cell_op<OP, FP, SM>(to_f64(a.y), to_f64(b.y));
                 plain_store(o, op + p);
             }
         }
@@ -108,8 +109,9 @@ template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const R* __restrict__ r,
                                                   double* __restrict__ out, size_t n, unsigned head) {
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
     if (head) {
-        if (blockIdx.x == 0 && threadIdx.x < head) out[threadIdx.x] = cell_op<OP, FP>(to_f64(l[threadIdx.x]), to_f64(r[threadIdx.x]));
+        if (blockIdx.x == 0 && threadIdx.x < head) out[threadIdx.x] = cell_op<OP, FP, SM>(to_f64(l[threadIdx.x]), to_f64(r[threadIdx.x]));
         l += head;
         r += head;
         out += head;
@@ -117,7 +119,7 @@ __device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const
     }
     binop_direct_tile<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n >> 1, two_front_tile());
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
-        out[n - 1] = cell_op<OP, FP>(to_f64(l[n - 1]), to_f64(r[n - 1]));
+        out[n - 1] = cell_op<OP, FP, SM>(to_f64(l[n - 1]), to_f64(r[n - 1]));
 }
 
 template <typename L, int OP, int U, bool NT_ST, bool NT_LD>
@@ -174,9 +176,10 @@ template <typename L, typename R, int OP>
 __global__ __launch_bounds__(kBlock) void k_binop_cellwise(const L* __restrict__ l, const R* __restrict__ r,
                                                            double* __restrict__ out, size_t n) {
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
     const size_t stride = size_t(gridDim.x) * kBlock;
     for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride)
-        out[i] = cell_op<OP, FP>(to_f64(l[i]), to_f64(r[i]));
+        out[i] = cell_op<OP, FP, SM>(to_f64(l[i]), to_f64(r[i]));
 }
 
 template <typename L, int OP>
@@ -215,6 +218,7 @@ __device__ __forceinline__ void binop_lds_body(const L* __restrict__ l, const R*
     using R2 = vec<R, 2>;
     using D2 = vec<double, 2>;
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
     constexpr bool SL = Staged<L>::value, SR = Staged<R>::value;
 
     __shared__ __attribute__((aligned(16))) unsigned char slab_l[kWavesPerBlock][Staged<L>::kSlabBytes];
@@ -262,15 +266,15 @@ __device__ __forceinline__ void binop_lds_body(const L* __restrict__ l, const R*
 #pragma unroll
         for (int j = 0; j < kLdsChunks; ++j) {
             D2 o;
-            o.x = cell_op<OP, FP>(to_f64(a[j].x), to_f64(b[j].x));
-            o.y = cell_op<OP, FP>(to_f64(a[j].y), to_f64(b[j].y));
+            o.x = cell_op<OP, FP, SM>(to_f64(a[j].x), to_f64(b[j].x));
+            o.y = cell_op<OP, FP, SM>(to_f64(a[j].y), to_f64(b[j].y));
             store_vec<NT_ST>(o2 + j * kWave + lane, o);
         }
     }
     // ragged tail (< one wave tile): cell-wise by workgroup 0
     if (blockIdx.x == 0)
         for (size_t i = nfull * kLdsWaveCells + threadIdx.x; i < n; i += kBlock)
-            out[i] = cell_op<OP, FP>(to_f64(l[i]), to_f64(r[i]));
+            out[i] = cell_op<OP, FP, SM>(to_f64(l[i]), to_f64(r[i]));
 }
 
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
@@ -318,9 +322,10 @@ __global__ __launch_bounds__(kBlock) void k_masked_binop_cellwise(const L* __res
                                                                   const R* __restrict__ r, const uint8_t* __restrict__ rm,
                                                                   double* __restrict__ out, uint8_t* __restrict__ om, size_t n) {
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
+    constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
     const size_t stride = size_t(gridDim.x) * kBlock;
     for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
-        out[i] = cell_op<OP, FP>(to_f64(l[i]), to_f64(r[i]));
+        out[i] = cell_op<OP, FP, SM>(to_f64(l[i]), to_f64(r[i]));
         om[i] = lm[i] & rm[i];
     }
 }

@@ -161,3 +161,47 @@ def test_map_kernels_every_instantiation(ec, pool, map_u, vector, off):
     finally:
         L.ec_tune_set(b"map_u", 2)
         L.ec_tune_set(b"unaligned_vector", 1)
+
+
+SMALL = {  # cell type -> (lowest, highest) cell value
+    "UInt8": (0, 255), "Int8": (-128, 127), "UInt16": (0, 65535), "Int16": (-32768, 32767),
+}
+
+
+@pytest.mark.parametrize("lname", list(SMALL))
+@pytest.mark.parametrize("rname", list(SMALL))
+def test_small_integer_divide_is_exact_for_every_operand_pair(ec, lname, rname):
+    """The divide of two cells of at most 16 bits uses a 6-instruction sequence (ec_device.hpp div_small_int) instead
+    of the IEEE expansion.  Its operand space is small enough to try EVERY pair: each (a, b) of the two cell types
+    goes through ec_binop (short sequence) and, widened to f64 first, through the f64 ÷ f64 kernel (IEEE expansion,
+    the path the oracle pins on all other tests); the two results must agree bit for bit on the device."""
+    import torch
+    L = ec.lib()
+    chk = ec._ffi.check
+    lt, rt = getattr(ec, lname), getattr(ec, rname)
+    tdt = {"UInt8": torch.uint8, "Int8": torch.int8, "UInt16": torch.uint16, "Int16": torch.int16}
+    (llo, lhi), (rlo, rhi) = SMALL[lname], SMALL[rname]
+    na, nb = lhi - llo + 1, rhi - rlo + 1
+    a_vals = torch.arange(llo, lhi + 1, dtype=torch.int32, device="cuda")
+    rows = max(1, min(nb, (1 << 27) // na))  # b-values per chunk: at most 2^27 cells at a time
+    for b0 in range(rlo, rhi + 1, rows):
+        nb_c = min(rows, rhi + 1 - b0)
+        n = na * nb_c
+        a = a_vals.repeat(nb_c).to(tdt[lname])
+        b = torch.arange(b0, b0 + nb_c, dtype=torch.int32, device="cuda").repeat_interleave(na).to(tdt[rname])
+        fast = torch.empty(n, dtype=torch.float64, device="cuda")
+        a64, b64, ref = torch.empty_like(fast), torch.empty_like(fast), torch.empty_like(fast)
+        torch.cuda.synchronize()
+        chk(L.ec_binop(ec.DIV, lt, a.data_ptr(), rt, b.data_ptr(), n, fast.data_ptr(), None))
+        chk(L.ec_convert(lt, a.data_ptr(), ec.Float64, a64.data_ptr(), n, None))
+        chk(L.ec_convert(rt, b.data_ptr(), ec.Float64, b64.data_ptr(), n, None))
+        chk(L.ec_binop(ec.DIV, ec.Float64, a64.data_ptr(), ec.Float64, b64.data_ptr(), n, ref.data_ptr(), None))
+        order = C.c_int32(7)
+        chk(L.ec_buffer_cmp(ec.Float64, fast.data_ptr(), n, ec.Float64, ref.data_ptr(), n, C.byref(order), None))
+        assert order.value == 0, (lname, rname, b0)
+    # and a slice against the CPU oracle, zeros in the divisor included
+    l = np.arange(llo, lhi + 1).astype(ec.NP_DTYPES[lt])
+    for bv in (0, 1, rlo, rhi, 3, 7):
+        r = np.full(l.size, bv).astype(ec.NP_DTYPES[rt])
+        got = (ec.CellBuffer.from_vec(l) / ec.CellBuffer.from_vec(r)).to_numpy()
+        assert_f64_bits_equal(got, eco.f_binop(eco.DIV, l, r))
