@@ -81,6 +81,21 @@ __device__ __forceinline__ double fused_cell_t(double x, double y, double z, dou
     return cell_op<O2, true>(t1, t2);
 }
 
+// Chains of the NDVI shape on cells of at most 16 bits: `(x ± y) / (z ± w)` or `(x ± y) / z`.  The sums and
+// differences are exact integers in [-131070, 131070], no NaN can reach the divide, and div_small_int is proven
+// bit-exact on that whole square as well (68,717,903,881 pairs, tools/div_small_check.hip) — so the chain needs
+// 2 adds and the 6-instruction divide instead of three IEEE steps with their NaN fix-ups.
+template <int O1, int O2, int O3>
+struct is_ndvi_shape {
+    static constexpr bool value = O2 == EC_DIV && (O1 == EC_ADD || O1 == EC_SUB) && (O3 == EC_ADD || O3 == EC_SUB || O3 == kOpNone);
+};
+template <int O1, int O3>
+__device__ __forceinline__ double ndvi_shape_small_int(double x, double y, double z, double w) {
+    const double t1 = O1 == EC_ADD ? x + y : x - y;
+    const double t2 = O3 == kOpNone ? z : (O3 == EC_ADD ? z + w : z - w);
+    return div_small_int(t1, t2);
+}
+
 constexpr int kFusedU = 4;  // pairs per lane per tile: the fused kernels carry more per-lane setup than k_binop_direct
 
 // mask phase: AND of the distinct operand masks (src/masked/masked_buffer.rs:333 applied per step),
@@ -125,6 +140,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
     const bool ld_x = !fa.is_sc[0], ld_y = !fa.is_sc[1] && fa.alias[1] == 1, ld_z = !fa.is_sc[2] && fa.alias[2] == 2,
                ld_w = has_w && !fa.is_sc[3] && fa.alias[3] == 3;
     const bool full = tile * TILE + TILE <= npairs;  // every pair of the tile exists: no per-pair guards
+    constexpr bool kSmallShape = is_small_int<T>::value && is_ndvi_shape<O1, O2, O3>::value;
+    const bool small_ints = kSmallShape && !(fa.is_sc[0] | fa.is_sc[1] | fa.is_sc[2] | (has_w ? fa.is_sc[3] : 0));  // no scalar operand
     T2 x[kFusedU] = {}, y[kFusedU] = {}, z[kFusedU] = {}, w[kFusedU] = {};
 #pragma unroll
     for (int j = 0; j < kFusedU; ++j) {
@@ -148,8 +165,15 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
             const D2 vz = fa.is_sc[2] ? D2{fa.sc[2], fa.sc[2]} : D2{to_f64(zz.x), to_f64(zz.y)};
             const D2 vw = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : D2{to_f64(ww.x), to_f64(ww.y)};
             D2 o;
-            o.x = fused_cell_t<O1, O2, O3>(vx.x, vy.x, vz.x, vw.x);
-            o.y = fused_cell_t<O1, O2, O3>(vx.y, vy.y, vz.y, vw.y);
+            if (small_ints) {  // launch-uniform
+                if constexpr (kSmallShape) {
+                    o.x = ndvi_shape_small_int<O1, O3>(vx.x, vy.x, vz.x, vw.x);
+                    o.y = ndvi_shape_small_int<O1, O3>(vx.y, vy.y, vz.y, vw.y);
+                }
+            } else {
+                o.x = fused_cell_t<O1, O2, O3>(vx.x, vy.x, vz.x, vw.x);
+                o.y = fused_cell_t<O1, O2, O3>(vx.y, vy.y, vz.y, vw.y);
+            }
             nt_store(o, op + pr);
         }
     }

@@ -205,3 +205,46 @@ def test_small_integer_divide_is_exact_for_every_operand_pair(ec, lname, rname):
         r = np.full(l.size, bv).astype(ec.NP_DTYPES[rt])
         got = (ec.CellBuffer.from_vec(l) / ec.CellBuffer.from_vec(r)).to_numpy()
         assert_f64_bits_equal(got, eco.f_binop(eco.DIV, l, r))
+
+
+@pytest.mark.parametrize("tname", ["UInt16", "Int16"])
+def test_fused_ndvi_small_integer_divide_is_exact_for_every_numerator_and_denominator(ec, tname):
+    """`(x - y) / (z + w)` on 16-bit cells runs as 2 adds + the 6-instruction divide (ec_fused_kernels.hpp).  Every
+    (numerator, denominator) such cells can produce is enumerated — 131071² pairs — and the fused kernel is compared on
+    the device with the eager chain (three launches, IEEE divide of the f64 temporaries)."""
+    import torch
+    L = ec.lib()
+    chk = ec._ffi.check
+    ct = getattr(ec, tname)
+    tdt = {"UInt16": torch.uint16, "Int16": torch.int16}[tname]
+    lo, hi = SMALL[tname]
+    t1_lo, t1_hi, t2_lo, t2_hi = lo - hi, hi - lo, 2 * lo, 2 * hi
+    n1 = t1_hi - t1_lo + 1
+    t1 = torch.arange(t1_lo, t1_hi + 1, dtype=torch.int32, device="cuda")
+    if lo == 0:
+        x1, y1 = t1.clamp(min=0), (-t1).clamp(min=0)
+    else:
+        x1 = torch.div(t1, 2, rounding_mode="floor")
+        y1 = x1 - t1
+    assert int(x1.min()) >= lo and int(x1.max()) <= hi and int(y1.min()) >= lo and int(y1.max()) <= hi
+    rows = max(1, (1 << 27) // n1)
+    dt4 = (C.c_uint8 * 4)(ct, ct, ct, ct)
+    for b0 in range(t2_lo, t2_hi + 1, rows):
+        nb = min(rows, t2_hi + 1 - b0)
+        n = n1 * nb
+        t2 = torch.arange(b0, b0 + nb, dtype=torch.int32, device="cuda")
+        z1 = torch.div(t2, 2, rounding_mode="floor")
+        w1 = t2 - z1
+        x, y = x1.repeat(nb).to(tdt), y1.repeat(nb).to(tdt)
+        z, w = z1.repeat_interleave(n1).to(tdt), w1.repeat_interleave(n1).to(tdt)
+        fused = torch.empty(n, dtype=torch.float64, device="cuda")
+        num, den, ref = torch.empty_like(fused), torch.empty_like(fused), torch.empty_like(fused)
+        torch.cuda.synchronize()
+        p4 = (C.c_void_p * 4)(x.data_ptr(), y.data_ptr(), z.data_ptr(), w.data_ptr())
+        chk(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, None, n, fused.data_ptr(), None))
+        chk(L.ec_binop(ec.SUB, ct, x.data_ptr(), ct, y.data_ptr(), n, num.data_ptr(), None))
+        chk(L.ec_binop(ec.ADD, ct, z.data_ptr(), ct, w.data_ptr(), n, den.data_ptr(), None))
+        chk(L.ec_binop(ec.DIV, ec.Float64, num.data_ptr(), ec.Float64, den.data_ptr(), n, ref.data_ptr(), None))
+        order = C.c_int32(7)
+        chk(L.ec_buffer_cmp(ec.Float64, fused.data_ptr(), n, ec.Float64, ref.data_ptr(), n, C.byref(order), None))
+        assert order.value == 0, (tname, b0)

@@ -4,6 +4,7 @@
 // a / b has only 98304² possible inputs, so a shorter instruction sequence than the compiler's IEEE expansion
 // (div_scale x2, rcp, 4 fma, mul, fma, div_fmas, div_fixup) can be PROVEN bit-exact by trying them all.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -ffp-contract=off tools/div_small_check.hip -o tools/div_small_check
+//   (add -DLO=-131070 -DHI=131070 for the range of sums and differences of two 16-bit cells: 68,717,903,881 pairs)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -26,7 +27,11 @@ __device__ __forceinline__ double div_small(double a, double b) {
     return q;
 }
 
-constexpr int LO = -32768, HI = 65535, SPAN = HI - LO + 1;  // 98304 values: every i8/u8/i16/u16 cell
+#ifndef LO
+#define LO (-32768)  // default: every i8 / u8 / i16 / u16 cell value (98304 of them)
+#define HI 65535     // -DLO=-131070 -DHI=131070: sums and differences of two such cells (the fused NDVI shape)
+#endif
+constexpr int SPAN = HI - LO + 1;
 
 template <int NEWTON>
 __global__ void k_check(unsigned long long* bad, unsigned long long* first_bad) {
@@ -39,7 +44,7 @@ __global__ void k_check(unsigned long long* bad, unsigned long long* first_bad) 
         const bool same = __builtin_bit_cast(uint64_t, ref) == __builtin_bit_cast(uint64_t, got) || (ref != ref && got != got && b != 0);
         if (!same) {
             ++local;
-            atomicMin(first_bad, (unsigned long long)((ai << 20) | (unsigned long long)(b - LO)));
+            atomicMin(first_bad, (unsigned long long)((ai << 24) | (unsigned long long)(b - LO)));
         }
     }
     if (local) atomicAdd(bad, local);
@@ -66,7 +71,7 @@ int main() {
         CK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
         CK(hipMemcpy(&hf, first, 8, hipMemcpyDeviceToHost));
         printf("newton steps %d: %llu mismatches of %llu pairs (%.1f ms)", newton, hb, (unsigned long long)SPAN * SPAN, ms);
-        if (hb) printf("; first at a=%lld b=%lld", (long long)(hf >> 20) + LO, (long long)(hf & 0xFFFFF) + LO);
+        if (hb) printf("; first at a=%lld b=%lld", (long long)(hf >> 24) + LO, (long long)(hf & 0xFFFFFF) + LO);
         printf("\n");
     }
     return 0;
