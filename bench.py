@@ -9,6 +9,7 @@ needs no data-path collective.  Scaling is therefore "strong": the raster is
 fixed at 16384² (north_star) and each rank owns rows/N of it.
 
   python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus N --steps K --warmup W          (launches its own N ranks, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -167,17 +168,33 @@ def e2e_pipelined(torch, ec, L, a, b, out, n: int, chunk: int = 1 << 25) -> dict
 
 
 def recorded_traffic(cells_per_launch: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/traffic.json, corrected as MI355X_MICROARCH.md §HBM prescribes); None if absent."""
+    """(HBM bytes per launch, where the figure comes from) of the dominant kernel.  PMC counters cannot be read
+    from inside this process, so this is a RECORDED figure, not a live one: the committed rocprofv3 --pmc passes
+    over this same command (profiles/traffic.json: kernel signature, commit and method; corrected as
+    MI355X_MICROARCH.md §HBM prescribes).  (None, None) when no record matches the launch size."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             rec = json.load(f)
         e = rec.get("binop_div_u8_u16", {})
         if e.get("cells_per_launch") == cells_per_launch:
-            return e.get("hbm_bytes_per_launch")
+            return e.get("hbm_bytes_per_launch"), f"recorded profiles/traffic.json @{e.get('commit', '?')} (round {e.get('round', '?')}), not measured in this run"
     except Exception:
         pass
-    return None
+    return None, None
+
+
+def verify_slices(workload: str, env: dict, cells: int = 1 << 20):
+    """Bit-exact check of the timed output against numpy's IEEE f64 divide on slices at both ends of the shard."""
+    import numpy as np
+    a, b, out, n = env["a"], env["b"], env["out"], env["n"]
+    k = min(cells, n)
+    for lo in {0, n - k}:
+        ha, hb, ho = a.shard(lo, k).to_numpy(), b.shard(lo, k).to_numpy(), out.shard(lo, k).to_numpy()
+        with np.errstate(all="ignore"):
+            exp = ha.astype(np.float64) / hb.astype(np.float64)
+        if not np.array_equal(exp.view(np.uint64), ho.view(np.uint64)):
+            return False
+    return True
 
 
 class _StdoutToStderr:
@@ -195,8 +212,36 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as fresh child
+    processes (`python -m torch.distributed.run ... bench.py <same flags>`, one rank per GPU) and return their
+    exit code.  Runs before this process makes any GPU call — it only counts the devices, which does not
+    initialise the runtime — and never replaces itself: the ranks are children, rank 0's JSON line reaches
+    this process's stdout through the inherited descriptor."""
+    import socket
+    import subprocess
+
+    import torch
+
+    ndev = torch.cuda.device_count()
+    if not args.single_device and ndev < args.gpus:
+        sys.stderr.write(f"bench.py --gpus {args.gpus}: this box shows {ndev} HIP device(s); one rank per GPU needs "
+                         f"{args.gpus} (there is no CPU fallback; --single-device --backend gloo is the 1-GPU rehearsal)\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     # the host driver of this pool only supports dmabuf IPC; RCCL fails without it (already exported on the boxes)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
@@ -205,10 +250,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world  # under a launcher the launcher's world size is authoritative
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     dev = 0 if args.single_device else local_rank
@@ -367,15 +409,33 @@ def main():
     barrier()                             # closing bracket: every rank is done before anything else happens
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream
 
-    tt = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device="cuda")
+    # ---- the timed output is checked, outside `value`: a slice at each end of this rank's shard against
+    # numpy's IEEE f64 arithmetic on the same operands (the oracle itself checks it in the cpu_baseline leg)
+    verified = verify_slices(args.workload, locals()) if args.workload == "div_u8_u16" else None
+
+    # per-rank record -> every rank: [elapsed s, device ms, cells, verified]
+    mine = torch.tensor([elapsed, dev_ms, float(n), 1.0 if verified in (None, True) else 0.0], dtype=torch.float64)
     if use_dist:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, dev_ms = float(tt[0]), float(tt[1])
+        dev_t = "cuda" if args.backend == "nccl" else "cpu"
+        gathered = [torch.empty(4, dtype=torch.float64, device=dev_t) for _ in range(world)]
+        dist.all_gather(gathered, mine.to(dev_t))
+        per_rank = [g.cpu().tolist() for g in gathered]
+    else:
+        per_rank = [mine.tolist()]
+    elapsed = max(r[0] for r in per_rank)          # MAX over ranks
+    slowest = max(range(len(per_rank)), key=lambda i: per_rank[i][1])
+    dev_ms = per_rank[slowest][1]
+    if verified is not None:
+        verified = all(r[3] == 1.0 for r in per_rank)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         launch_ms = dev_ms / args.steps
-        achieved = bytes_per_cell * n / (launch_ms * 1e-3) / 1e9
+        n_slowest = int(per_rank[slowest][2])
+        achieved = bytes_per_cell * n_slowest / (launch_ms * 1e-3) / 1e9  # the slowest GPU's launch: its bytes / its time
+        traffic, traffic_source = recorded_traffic(n_slowest) if (args.workload == "div_u8_u16" and world == 1) else (None, None)
+        per_gpu = [{"rank": i, "cells": int(r[2]), "launch_ms": r[1] / args.steps,
+                    "frac": bytes_per_cell * r[2] / (r[1] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS} for i, r in enumerate(per_rank)]
         res = {
             "metric": METRIC if args.workload == "div_u8_u16" else f"Gcells/s ({args.workload})",
             "value": total_cells / (elapsed / args.steps) / 1e9,
@@ -388,16 +448,22 @@ def main():
             "dtype": "f64" if args.workload != "minmax" else "u16",
             "data": "synthetic",
             "config": {"workload": wl, "rows": rows_total, "cols": side, "cells": total_cells,
-                       "cells_per_gpu": n, "sharding": "contiguous row-block per rank, no data-path collective",
+                       "cells_per_gpu": n, "cells_per_rank": [int(r[2]) for r in per_rank], "sharding": "contiguous row-block per rank, no data-path collective",
                        "inputs": "splitmix64 counter streams generated on device, resident in HBM",
                        "kernel_variant": "lds" if (args.variant or 0) == 1 else "direct",
                        "clock_ramp_steps": ramp, "launch": "hipGraph of the K steps" if args.graph else "K stream launches"},
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": recorded_traffic(n) if (args.workload == "div_u8_u16" and world == 1) else None,
-                         "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": n,
-                         "launch_ms": launch_ms, "timer": "hipEvent pair on the launch stream over the timed region / steps"},
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_cell": bytes_per_cell, "cells_per_launch": n_slowest,
+                         "launch_ms": launch_ms, "timer": "hipEvent pair on the launch stream over the timed region / steps"
+                                                          + ("; the slowest rank's launch" if world > 1 else ""),
+                         "per_gpu": per_gpu},
         }
+        if verified is not None:
+            res["verified"] = verified
+            res["config"]["verified_how"] = ("after the timed region every rank compares 2^20 cells at each end of its output shard "
+                                             "bit for bit with numpy's f64 divide of the same operands")
         if args.e2e and world == 1 and args.workload == "div_u8_u16":
             import numpy as np
             ha, hb = a.to_numpy(), b.to_numpy()
@@ -437,6 +503,16 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline and args.workload == "div_u8_u16":
             res["cpu_baseline"] = cpu_baseline(side, args.cpu_seconds)
+            # the oracle as the checker of the timed output (same leg, outside `value`): 2^20 cells, bit for bit,
+            # against both of its forms (reference-shaped and typed loop)
+            import numpy as np
+            from oracle import eco
+            k = min(1 << 20, n)
+            ha, hb, ho = a.shard(0, k).to_numpy(), b.shard(0, k).to_numpy(), out.shard(0, k).to_numpy()
+            ok = np.array_equal(eco.f_binop(eco.DIV, ha, hb).view(np.uint64), ho.view(np.uint64)) and \
+                np.array_equal(eco.binop(eco.DIV, ha[:65536], hb[:65536]).view(np.uint64), ho[:65536].view(np.uint64))
+            res["cpu_baseline"]["oracle_check_of_timed_output"] = bool(ok)
+            res["verified"] = bool(res.get("verified", True) and ok)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

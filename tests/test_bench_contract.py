@@ -45,3 +45,54 @@ def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
     assert all(0 < rs[k] < 8000.0 for k in ("same_mix_add_u8_u16_GBps", "write_only_fill_f64_GBps", "read_only_min_max_f64_GBps"))
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "Gcells/s" and cb["value"] > 0 and cb["sample"]
+
+
+def _one_line(r):
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_n_launches_itself_and_names_the_device_count():
+    """`python bench.py --gpus 2` with no launcher around it must start its own ranks; on a box with fewer than
+    two GPUs it fails loudly, naming how many it saw, and never asks for torchrun."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two HIP devices present: the launch would succeed")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert f"shows {torch.cuda.device_count()} HIP device(s)" in r.stderr and "torch.distributed.run" not in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_self_launched_two_ranks_rehearsal_on_one_gpu():
+    """The N>1 control flow end to end from a bare `python bench.py --gpus 2`: self-launch of two fresh ranks,
+    row-block shards, per-rank gather, MAX-over-ranks time, one JSON line.  Both ranks share device 0 and talk
+    over gloo (RCCL refuses two ranks on one GPU) — a rehearsal of the flow, not a scaling measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--single-device", "--side", "4096",
+                        "--steps", "5", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=800)
+    d = _one_line(r)
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["verified"] is True
+    assert d["config"]["cells_per_rank"] == [4096 * 2048, 4096 * 2048] and d["config"]["cells"] == 4096 * 4096
+    pg = d["roofline"]["per_gpu"]
+    assert [g["rank"] for g in pg] == [0, 1] and all(g["cells"] == 4096 * 2048 and 0 < g["frac"] < 1 for g in pg)
+    assert abs(d["roofline"]["launch_ms"] - max(g["launch_ms"] for g in pg)) < 1e-12
+    assert "cpu_baseline" not in d  # rank 0 at N=1 only
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_rccl_path_with_one_rank():
+    """backend nccl (= RCCL) through the same distributed code path, with the one rank a 1-GPU box allows."""
+    env = dict(os.environ, EC_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--side", "4096", "--steps", "5", "--warmup", "1", "--no-cpu-baseline",
+                        "--workload", "minmax"], env=env, capture_output=True, text=True, timeout=500)
+    d = _one_line(r)
+    assert d["n_gpus"] == 1 and d["dtype"] == "u16" and len(d["roofline"]["per_gpu"]) == 1
