@@ -1,6 +1,6 @@
-// ec_abi.hip — the extern "C" surface of liberased_cells_hip.so (include/erased_cells.h):
-// runtime (device, memory, errors), the type lattice, and the type-erased
-// dispatch of every kernel family except the four binary ops (ec_binop_*.hip).
+// ec_abi.hip — the extern "C" compute surface of liberased_cells_hip.so (include/erased_cells.h):
+// the type lattice and the type-erased dispatch of every kernel family except the four binary ops
+// (ec_binop_*.hip) and the fused chains (ec_fused*.hip).  Devices, memory, streams: ec_runtime.hip.
 //
 // There is no CPU fallback anywhere in this library: without a HIP device every
 // compute entry point returns EC_ERR_HIP / EC_ERR_NOT_INITIALIZED.
@@ -21,78 +21,9 @@
 
 namespace ecd {
 
-// ------------------------------------------------------------------ state
-static thread_local std::string t_err;
-static thread_local int t_narrow_src = -1, t_narrow_dst = -1;
-
-static std::mutex g_mu;
-static bool g_inited = false;
-static int g_device = -1;
-static int g_cus = 256;
 static_assert(kMaxReduceBlocks <= kFinalizeMaxParts, "the finalize kernels read at most kFinalizeMaxParts partials");
-static Tuning g_tuning;
-static std::map<hipStream_t, Scratch> g_scratch;
 
-Tuning& tuning() { return g_tuning; }
-int device_cus() { return g_cus; }
-
-ec_status set_error(ec_status code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    t_err = buf;
-    return code;
-}
-
-ec_status set_narrowing(int src, int dst) {
-    static const char* names[EC_NTYPES] = {"UInt8", "UInt16", "UInt32", "UInt64", "Int8",
-                                           "Int16", "Int32", "Int64", "Float32", "Float64"};
-    t_narrow_src = src;
-    t_narrow_dst = dst;
-    // message text of Error::NarrowingError (src/error.rs:14)
-    return set_error(EC_ERR_NARROWING, "Invalid narrowing from cell-type %s to %s", names[src], names[dst]);
-}
-
-ec_status check_hip(hipError_t e, const char* what) {
-    if (e == hipSuccess) return EC_OK;
-    return set_error(EC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
-}
-
-ec_status check_launch(const char* what) { return check_hip(hipGetLastError(), what); }
-
-// HIP's current device is per host thread: bind every calling thread to the library's device once.
-static thread_local int t_bound_device = -1;
-
-static ec_status ensure_init() {
-    if (!g_inited) return set_error(EC_ERR_NOT_INITIALIZED, "ec_init() has not been called (no HIP device bound)");
-    if (t_bound_device != g_device) {
-        ec_status st = check_hip(hipSetDevice(g_device), "hipSetDevice");
-        if (st != EC_OK) return st;
-        t_bound_device = g_device;
-    }
-    return EC_OK;
-}
-
-ec_status ensure_ready() { return ensure_init(); }
-
-ec_status get_scratch(hipStream_t s, Scratch* out) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_scratch.find(s);
-    if (it == g_scratch.end()) {
-        Scratch sc;
-        ec_status st = check_hip(hipMalloc(reinterpret_cast<void**>(&sc.dev), (2 * kMaxReduceBlocks + 4) * sizeof(int64_t)),
-                                 "hipMalloc(scratch)");
-        if (st != EC_OK) return st;
-        st = check_hip(hipHostMalloc(reinterpret_cast<void**>(&sc.host), 4 * sizeof(int64_t), hipHostMallocDefault),
-                       "hipHostMalloc(scratch)");
-        if (st != EC_OK) { (void)hipFree(sc.dev); return st; }
-        it = g_scratch.emplace(s, sc).first;
-    }
-    *out = it->second;
-    return EC_OK;
-}
+static ec_status ensure_init() { return ensure_ready(); }
 
 static inline hipStream_t S(ec_stream s) { return static_cast<hipStream_t>(s); }
 
@@ -109,7 +40,7 @@ static ec_status launch_map(const Fn& fn, size_t n, bool aligned, hipStream_t s,
     if (!aligned) {
         k_map_cellwise<Fn><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fn, n);
     } else {
-        switch (g_tuning.map_u) {  // groups of 16 B per lane per tile
+        switch (tuning().map_u) {  // groups of 16 B per lane per tile
             case 1: launch_map_u<Fn, 1>(fn, n, s); break;
             case 4: launch_map_u<Fn, 4>(fn, n, s); break;
             default: launch_map_u<Fn, 2>(fn, n, s); break;
@@ -162,7 +93,7 @@ static ec_status launch_min_max(const void* p, const uint8_t* mask, size_t n, in
     unsigned grid = 0;
     if (n > 0) {
         const bool al = aligned16(p, p, p) && (!mask || aligned_to(mask, 16 / sizeof(T)));
-        int cap = g_cus * g_tuning.reduce_bpc;
+        int cap = device_cus() * tuning().reduce_bpc;
         if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
         if (al) {
             const unsigned head = reduce_head(p, sizeof(T), n);
@@ -300,161 +231,6 @@ extern "C" ec_status ec_shard_range(uint64_t n_rows, uint64_t n_cols, uint32_t s
     return EC_OK;
 }
 
-// =================================================================== runtime
-extern "C" int32_t ec_abi_version(void) { return EC_ABI_VERSION; }
-
-extern "C" ec_status ec_init(int32_t device) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_inited && g_device == device) {
-        if (t_bound_device != device && hipSetDevice(device) == hipSuccess) t_bound_device = device;
-        return EC_OK;
-    }
-    if (g_inited)  // one process per GPU: scratch and pooled memory belong to the bound device
-        return set_error(EC_ERR_ARG, "ec_init: already bound to device %d; call ec_shutdown() before binding device %d", g_device, device);
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0)
-        return set_error(EC_ERR_HIP, "ec_init: no HIP device (%s)", e == hipSuccess ? "count == 0" : hipGetErrorString(e));
-    if (device < 0 || device >= count) return set_error(EC_ERR_ARG, "ec_init: device %d of %d", device, count);
-    ec_status st = check_hip(hipSetDevice(device), "hipSetDevice");
-    if (st != EC_OK) return st;
-    hipDeviceProp_t prop;
-    st = check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
-    if (st != EC_OK) return st;
-    g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    g_device = device;
-    g_inited = true;
-    t_bound_device = device;
-    // Stream-ordered allocations (ec_alloc_async) come from the device's default memory pool; keep freed
-    // blocks cached in the pool instead of returning them to the OS at every synchronisation.
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-        uint64_t keep = ~0ull;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
-    (void)hipGetLastError();
-    return EC_OK;  // (reduction scratch for the default stream is created by ec_prepare_stream / first use)
-}
-
-extern "C" ec_status ec_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_scratch) {
-        (void)hipFree(kv.second.dev);
-        (void)hipHostFree(kv.second.host);
-    }
-    g_scratch.clear();
-    g_inited = false;
-    g_device = -1;
-    return EC_OK;
-}
-
-extern "C" const char* ec_last_error_string(void) { return t_err.c_str(); }
-
-extern "C" ec_status ec_last_narrowing(ec_dtype* src, ec_dtype* dst) {
-    if (!src || !dst || t_narrow_src < 0) return set_error(EC_ERR_ARG, "ec_last_narrowing: nothing recorded");
-    *src = static_cast<ec_dtype>(t_narrow_src);
-    *dst = static_cast<ec_dtype>(t_narrow_dst);
-    return EC_OK;
-}
-
-extern "C" ec_status ec_device_info(int32_t* n_cu, uint64_t* hbm_bytes, char* name, size_t name_cap) {
-    ec_status st = ensure_init();
-    if (st != EC_OK) return st;
-    hipDeviceProp_t prop;
-    st = check_hip(hipGetDeviceProperties(&prop, g_device), "hipGetDeviceProperties");
-    if (st != EC_OK) return st;
-    if (n_cu) *n_cu = prop.multiProcessorCount;
-    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
-    if (name && name_cap) { std::strncpy(name, prop.gcnArchName, name_cap - 1); name[name_cap - 1] = 0; }
-    return EC_OK;
-}
-
-extern "C" ec_status ec_alloc(void** dptr, size_t bytes) {
-    if (!dptr) return set_error(EC_ERR_ARG, "ec_alloc: null out pointer");
-    ec_status st = ensure_init();
-    if (st != EC_OK) return st;
-    *dptr = nullptr;
-    if (bytes == 0) return EC_OK;
-    return check_hip(hipMalloc(dptr, bytes), "hipMalloc");
-}
-extern "C" ec_status ec_free(void* dptr) { return dptr ? check_hip(hipFree(dptr), "hipFree") : EC_OK; }
-
-// Result buffers of eager operators are allocated per call (the reference `collect()`s a fresh Vec);
-// hipMalloc/hipFree cost 0.2-0.4 ms per pair — as much as the 16384² kernel itself — and hipFree
-// synchronises.  The stream-ordered pool makes both a queue operation (tools/alloc_cost.py).
-extern "C" ec_status ec_alloc_async(void** dptr, size_t bytes, ec_stream stream) {
-    if (!dptr) return set_error(EC_ERR_ARG, "ec_alloc_async: null out pointer");
-    ec_status st = ensure_init();
-    if (st != EC_OK) return st;
-    *dptr = nullptr;
-    if (bytes == 0) return EC_OK;
-    return check_hip(hipMallocAsync(dptr, bytes, S(stream)), "hipMallocAsync");
-}
-extern "C" ec_status ec_free_async(void* dptr, ec_stream stream) {
-    return dptr ? check_hip(hipFreeAsync(dptr, S(stream)), "hipFreeAsync") : EC_OK;
-}
-
-extern "C" ec_status ec_upload(void* dst_dev, const void* src_host, size_t bytes, ec_stream stream) {
-    if (bytes == 0) return EC_OK;
-    if (!dst_dev || !src_host) return set_error(EC_ERR_ARG, "ec_upload: null pointer");
-    ec_status st = check_hip(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, S(stream)), "hipMemcpyAsync(H2D)");
-    if (st != EC_OK) return st;
-    return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");  // src_host may be pageable
-}
-extern "C" ec_status ec_download(void* dst_host, const void* src_dev, size_t bytes, ec_stream stream) {
-    if (bytes == 0) return EC_OK;
-    if (!dst_host || !src_dev) return set_error(EC_ERR_ARG, "ec_download: null pointer");
-    ec_status st = check_hip(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync(D2H)");
-    if (st != EC_OK) return st;
-    return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
-}
-extern "C" ec_status ec_copy(void* dst_dev, const void* src_dev, size_t bytes, ec_stream stream) {
-    if (bytes == 0) return EC_OK;
-    if (!dst_dev || !src_dev) return set_error(EC_ERR_ARG, "ec_copy: null pointer");
-    return check_hip(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, S(stream)), "hipMemcpyAsync(D2D)");
-}
-extern "C" ec_status ec_stream_create(ec_stream* out) {
-    if (!out) return set_error(EC_ERR_ARG, "ec_stream_create: null out");
-    ec_status st = ensure_init();
-    if (st != EC_OK) return st;
-    hipStream_t s;
-    st = check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
-    if (st != EC_OK) return st;
-    *out = s;
-    return ec_prepare_stream(s);
-}
-
-extern "C" ec_status ec_prepare_stream(ec_stream stream) {
-    ec_status st = ensure_init();
-    if (st != EC_OK) return st;
-    Scratch sc;
-    return get_scratch(S(stream), &sc);  // allocates this stream's reduction scratch now, not at first use
-}
-extern "C" ec_status ec_stream_destroy(ec_stream s) {
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_scratch.find(S(s));
-        if (it != g_scratch.end()) {
-            (void)hipFree(it->second.dev);
-            (void)hipHostFree(it->second.host);
-            g_scratch.erase(it);
-        }
-    }
-    return check_hip(hipStreamDestroy(S(s)), "hipStreamDestroy");
-}
-extern "C" ec_status ec_stream_sync(ec_stream s) { return check_hip(hipStreamSynchronize(S(s)), "hipStreamSynchronize"); }
-
-extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
-    if (!key) return set_error(EC_ERR_ARG, "ec_tune_set: null key");
-    if (!std::strcmp(key, "binop_variant")) g_tuning.binop_variant = static_cast<int>(value);
-    else if (!std::strcmp(key, "reduce_bpc")) g_tuning.reduce_bpc = value > 0 ? static_cast<int>(value) : 8;
-    else if (!std::strcmp(key, "map_u")) g_tuning.map_u = static_cast<int>(value);
-    else if (!std::strcmp(key, "peel")) g_tuning.peel = static_cast<int>(value);
-    else if (!std::strcmp(key, "unaligned_vector")) g_tuning.unaligned_vector = value != 0;
-    else return set_error(EC_ERR_ARG, "ec_tune_set: unknown key '%s'", key);
-    return EC_OK;
-}
-
 // =================================================================== arithmetic
 #define EC_REQUIRE_INIT()               \
     do {                                \
@@ -575,6 +351,7 @@ extern "C" ec_status ec_min_max(ec_dtype t, const void* p, const uint8_t* mask_o
     Scratch sc;
     ec_status st = get_scratch(S(stream), &sc);
     if (st != EC_OK) return st;
+    std::lock_guard<std::mutex> turn(*sc.mu);  // the pinned result words are per stream: host threads sharing it take turns
     st = dispatch_min_max(t, p, mask_or_null, n, sc.dev_result(), S(stream));
     if (st != EC_OK) return st;
     st = check_hip(hipMemcpyAsync(sc.host, sc.dev_result(), 2 * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync");
@@ -587,7 +364,7 @@ extern "C" ec_status ec_min_max(ec_dtype t, const void* p, const uint8_t* mask_o
 // =================================================================== Ord / Eq
 template <typename W>
 static ec_status first_diff_w(const void* l, const void* r, size_t n, const Scratch& sc, hipStream_t s, unsigned* grid_out) {
-    int cap = g_cus * g_tuning.reduce_bpc;
+    int cap = device_cus() * tuning().reduce_bpc;
     if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
     const bool al = aligned16(l, r, r);
     const unsigned head = al ? reduce_head(l, sizeof(W), n) : 0u;
@@ -609,6 +386,7 @@ extern "C" ec_status ec_first_difference(ec_dtype t, const void* l, const void* 
     Scratch sc;
     ec_status st = get_scratch(S(stream), &sc);
     if (st != EC_OK) return st;
+    std::lock_guard<std::mutex> turn(*sc.mu);
     unsigned grid = 0;
     switch (ecl::size_of(t)) {
         case 1: st = first_diff_w<uint8_t>(l, r, n, sc, S(stream), &grid); break;
@@ -743,7 +521,7 @@ extern "C" ec_status ec_mask_counts_device(const uint8_t* m, size_t n, uint64_t*
     if (st != EC_OK) return st;
     unsigned grid = 0;
     if (n > 0) {
-        int cap = g_cus * g_tuning.reduce_bpc;
+        int cap = device_cus() * tuning().reduce_bpc;
         if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
         const bool al = aligned_to(m, 16);
         const unsigned head = al ? reduce_head(m, 1, n) : 0u;
@@ -764,6 +542,7 @@ extern "C" ec_status ec_mask_counts(const uint8_t* m, size_t n, uint64_t* n_true
     Scratch sc;
     ec_status st = get_scratch(S(stream), &sc);
     if (st != EC_OK) return st;
+    std::lock_guard<std::mutex> turn(*sc.mu);
     st = ec_mask_counts_device(m, n, reinterpret_cast<uint64_t*>(sc.dev_result()), stream);
     if (st != EC_OK) return st;
     st = check_hip(hipMemcpyAsync(sc.host, sc.dev_result(), 2 * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync");

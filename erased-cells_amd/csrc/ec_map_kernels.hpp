@@ -185,9 +185,11 @@ template <int KIND>  // 0 and, 1 or
 struct MaskBin {
     static constexpr int CPL = 16;
     struct In { u32x4 a, b; };
-    const uint8_t* __restrict__ l;
-    const uint8_t* __restrict__ r;
-    uint8_t* __restrict__ out;
+    // no __restrict__: the owned forms run in place (out == l; BitAnd/BitOr for Mask, mask.rs:118-127,142-151).
+    // Every lane loads a group and stores the same group, so aliasing is well defined without it.
+    const uint8_t* l;
+    const uint8_t* r;
+    uint8_t* out;
     __device__ __forceinline__ In load(size_t g) const {
         return In{nt_load(reinterpret_cast<const u32x4*>(l) + g),
                   nt_load(reinterpret_cast<const u32x4*>(r) + g)};
@@ -201,8 +203,8 @@ struct MaskBin {
 struct MaskNot {
     static constexpr int CPL = 16;
     using In = u32x4;
-    const uint8_t* __restrict__ m;
-    uint8_t* __restrict__ out;
+    const uint8_t* m;  // may alias out (Not for Mask, mask.rs:103-109)
+    uint8_t* out;
     __device__ __forceinline__ In load(size_t g) const { return nt_load(reinterpret_cast<const u32x4*>(m) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         nt_store(x ^ 0x01010101u, reinterpret_cast<u32x4*>(out) + g);

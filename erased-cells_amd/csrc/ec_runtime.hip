@@ -1,0 +1,412 @@
+// ec_runtime.hip — devices, memory, streams, errors and tuning of liberased_cells_hip.so.
+//
+// The runtime is per DEVICE: every device passed to ec_init() gets its own CU count, its own
+// library-owned stream-ordered memory pool and its own per-stream reduction scratch.  A host thread
+// works on one device at a time (its "current library device": the one of its last ec_init /
+// ec_set_device, by default the first device the process initialised); one process can therefore drive
+// one GPU (the one-rank-per-GPU shape of bench.py) or all eight (ec_shard_group_*, ec_sharded.hip).
+//
+// There is no CPU fallback: without a HIP device every compute entry point returns
+// EC_ERR_HIP / EC_ERR_NOT_INITIALIZED.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+
+#include "ec_runtime.hpp"
+
+namespace ecd {
+
+// ------------------------------------------------------------------ errors (thread-local)
+static thread_local std::string t_err;
+static thread_local int t_narrow_src = -1, t_narrow_dst = -1;
+
+ec_status set_error(ec_status code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    t_err = buf;
+    return code;
+}
+
+ec_status set_error_text(ec_status code, const std::string& text) {
+    t_err = text;
+    return code;
+}
+
+const std::string& last_error_text() { return t_err; }
+
+ec_status set_narrowing(int src, int dst) {
+    static const char* names[EC_NTYPES] = {"UInt8", "UInt16", "UInt32", "UInt64", "Int8",
+                                           "Int16", "Int32", "Int64", "Float32", "Float64"};
+    t_narrow_src = src;
+    t_narrow_dst = dst;
+    // message text of Error::NarrowingError (src/error.rs:14)
+    return set_error(EC_ERR_NARROWING, "Invalid narrowing from cell-type %s to %s", names[src], names[dst]);
+}
+
+ec_status check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return EC_OK;
+    return set_error(EC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+ec_status check_launch(const char* what) { return check_hip(hipGetLastError(), what); }
+
+// ------------------------------------------------------------------ per-device state
+struct ScratchEntry {
+    Scratch sc;
+    uint64_t stamp = 0;  // last use, for eviction
+};
+
+struct DeviceState {
+    int device = -1;
+    int cus = 256;
+    hipMemPool_t pool = nullptr;  // library-owned; nullptr = creation failed, the device's default pool serves (untouched)
+    std::map<hipStream_t, ScratchEntry> scratch;
+};
+
+// A foreign stream (torch's, a caller's) gets scratch at first use and nobody tells the library when it dies, so the
+// table is bounded: beyond kMaxScratchPerDevice streams the least recently used entry is released (hipFree waits for
+// the device, so no kernel can still be writing it; a stream used again later simply gets a fresh entry).
+constexpr size_t kMaxScratchPerDevice = 64;
+
+static std::mutex g_mu;
+static std::map<int, DeviceState> g_devs;
+static std::atomic<int> g_default_device{-1};
+static std::atomic<uint64_t> g_generation{1};  // bumped by ec_shutdown: invalidates every thread's cached binding
+static std::atomic<uint64_t> g_stamp{0};
+static Tuning g_tuning;
+
+static thread_local int t_device = -1;          // this thread's choice (ec_init / ec_set_device), -1 = process default
+static thread_local uint64_t t_generation = 0;
+static thread_local int t_active = -1;          // device bound by the last ensure_ready()
+static thread_local int t_cus = 256;
+
+Tuning& tuning() { return g_tuning; }
+int device_cus() { return t_cus; }
+int current_device() { return t_active; }
+
+static void free_scratch(Scratch& sc) {
+    (void)hipFree(sc.dev);
+    (void)hipHostFree(sc.host);
+    delete sc.mu;
+    sc = Scratch{};
+}
+
+ec_status ensure_ready() {
+    if (t_generation != g_generation.load(std::memory_order_acquire)) {
+        t_device = -1;
+        t_active = -1;
+        t_generation = g_generation.load(std::memory_order_acquire);
+    }
+    const int dev = t_device >= 0 ? t_device : g_default_device.load(std::memory_order_acquire);
+    if (dev < 0) return set_error(EC_ERR_NOT_INITIALIZED, "ec_init() has not been called (no HIP device bound)");
+    // HIP's current device is per host thread, and other code in the process (torch, the caller) may move it
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != dev) {
+        ec_status st = check_hip(hipSetDevice(dev), "hipSetDevice");
+        if (st != EC_OK) return st;
+    }
+    if (t_active != dev) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_devs.find(dev);
+        if (it == g_devs.end()) return set_error(EC_ERR_NOT_INITIALIZED, "device %d is not initialised (ec_init)", dev);
+        t_cus = it->second.cus;
+        t_active = dev;
+    }
+    return EC_OK;
+}
+
+ec_status get_scratch(hipStream_t s, Scratch* out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto dit = g_devs.find(t_active);
+    if (dit == g_devs.end()) return set_error(EC_ERR_NOT_INITIALIZED, "get_scratch: no device bound");
+    auto& table = dit->second.scratch;
+    auto it = table.find(s);
+    if (it == table.end()) {
+        if (table.size() >= kMaxScratchPerDevice) {
+            auto victim = table.begin();
+            for (auto k = table.begin(); k != table.end(); ++k)
+                if (k->second.stamp < victim->second.stamp) victim = k;
+            free_scratch(victim->second.sc);
+            table.erase(victim);
+        }
+        ScratchEntry e;
+        ec_status st = check_hip(hipMalloc(reinterpret_cast<void**>(&e.sc.dev), (2 * kMaxReduceBlocks + 4) * sizeof(int64_t)),
+                                 "hipMalloc(scratch)");
+        if (st != EC_OK) return st;
+        st = check_hip(hipHostMalloc(reinterpret_cast<void**>(&e.sc.host), 4 * sizeof(int64_t), hipHostMallocDefault),
+                       "hipHostMalloc(scratch)");
+        if (st != EC_OK) { (void)hipFree(e.sc.dev); return st; }
+        e.sc.mu = new std::mutex;
+        it = table.emplace(s, e).first;
+    }
+    it->second.stamp = ++g_stamp;
+    *out = it->second.sc;
+    return EC_OK;
+}
+
+static void set_pool_threshold(hipMemPool_t pool) {
+    uint64_t keep = static_cast<uint64_t>(g_tuning.pool_keep_mb.load()) << 20;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+}
+
+static inline hipStream_t S(ec_stream s) { return static_cast<hipStream_t>(s); }
+
+}  // namespace ecd
+
+using namespace ecd;
+
+// =================================================================== runtime
+extern "C" int32_t ec_abi_version(void) { return EC_ABI_VERSION; }
+
+extern "C" ec_status ec_init(int32_t device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    t_generation = g_generation.load();
+    if (g_devs.count(device)) {  // idempotent; also (re)binds the calling thread
+        t_device = device;
+        t_active = -1;
+        return EC_OK;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_error(EC_ERR_HIP, "ec_init: no HIP device (%s)", e == hipSuccess ? "count == 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return set_error(EC_ERR_ARG, "ec_init: device %d of %d", device, count);
+    ec_status st = check_hip(hipSetDevice(device), "hipSetDevice");
+    if (st != EC_OK) return st;
+    hipDeviceProp_t prop;
+    st = check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    if (st != EC_OK) return st;
+    DeviceState ds;
+    ds.device = device;
+    ds.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // Stream-ordered allocations (ec_alloc_async) come from a pool this library owns — the device's default pool,
+    // which other code in the process may use, is left alone.  Freed blocks stay cached up to the release
+    // threshold ("pool_keep_mb") instead of going back to the driver at every synchronisation.
+    hipMemPoolProps pp;
+    std::memset(&pp, 0, sizeof pp);
+    pp.allocType = hipMemAllocationTypePinned;
+    pp.handleTypes = hipMemHandleTypeNone;
+    pp.location.type = hipMemLocationTypeDevice;
+    pp.location.id = device;
+    if (hipMemPoolCreate(&ds.pool, &pp) == hipSuccess) set_pool_threshold(ds.pool);
+    else ds.pool = nullptr;
+    (void)hipGetLastError();
+    g_devs.emplace(device, ds);
+    int none = -1;
+    g_default_device.compare_exchange_strong(none, device);
+    t_device = device;
+    t_active = -1;
+    return EC_OK;  // (reduction scratch of a stream is created by ec_prepare_stream / first use)
+}
+
+extern "C" ec_status ec_set_device(int32_t device) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_devs.count(device)) return set_error(EC_ERR_NOT_INITIALIZED, "ec_set_device: device %d is not initialised (ec_init)", device);
+    }
+    t_generation = g_generation.load();
+    t_device = device;
+    return ensure_ready();
+}
+
+extern "C" ec_status ec_get_device(int32_t* device) {
+    if (!device) return set_error(EC_ERR_ARG, "ec_get_device: null out");
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    *device = t_active;
+    return EC_OK;
+}
+
+extern "C" ec_status ec_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_devs) {
+        if (hipSetDevice(kv.first) != hipSuccess) continue;
+        (void)hipDeviceSynchronize();
+        for (auto& se : kv.second.scratch) free_scratch(se.second.sc);
+        kv.second.scratch.clear();
+        if (kv.second.pool) {
+            (void)hipMemPoolTrimTo(kv.second.pool, 0);
+            (void)hipMemPoolDestroy(kv.second.pool);
+        }
+    }
+    (void)hipGetLastError();
+    g_devs.clear();
+    g_default_device.store(-1);
+    g_generation.fetch_add(1);
+    t_device = t_active = -1;
+    return EC_OK;
+}
+
+extern "C" const char* ec_last_error_string(void) { return t_err.c_str(); }
+
+extern "C" ec_status ec_last_narrowing(ec_dtype* src, ec_dtype* dst) {
+    if (!src || !dst || t_narrow_src < 0) return set_error(EC_ERR_ARG, "ec_last_narrowing: nothing recorded");
+    *src = static_cast<ec_dtype>(t_narrow_src);
+    *dst = static_cast<ec_dtype>(t_narrow_dst);
+    return EC_OK;
+}
+
+extern "C" ec_status ec_device_info(int32_t* n_cu, uint64_t* hbm_bytes, char* name, size_t name_cap) {
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    hipDeviceProp_t prop;
+    st = check_hip(hipGetDeviceProperties(&prop, t_active), "hipGetDeviceProperties");
+    if (st != EC_OK) return st;
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    if (name && name_cap) { std::strncpy(name, prop.gcnArchName, name_cap - 1); name[name_cap - 1] = 0; }
+    return EC_OK;
+}
+
+// ------------------------------------------------------------------ memory
+extern "C" ec_status ec_alloc(void** dptr, size_t bytes) {
+    if (!dptr) return set_error(EC_ERR_ARG, "ec_alloc: null out pointer");
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    *dptr = nullptr;
+    if (bytes == 0) return EC_OK;
+    return check_hip(hipMalloc(dptr, bytes), "hipMalloc");
+}
+extern "C" ec_status ec_free(void* dptr) { return dptr ? check_hip(hipFree(dptr), "hipFree") : EC_OK; }
+
+// Result buffers of eager operators are allocated per call (the reference `collect()`s a fresh Vec);
+// hipMalloc/hipFree cost 0.2-0.4 ms per pair — as much as the 16384² kernel itself — and hipFree
+// synchronises.  The stream-ordered pool makes both a queue operation (tools/alloc_cost.py).
+extern "C" ec_status ec_alloc_async(void** dptr, size_t bytes, ec_stream stream) {
+    if (!dptr) return set_error(EC_ERR_ARG, "ec_alloc_async: null out pointer");
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    *dptr = nullptr;
+    if (bytes == 0) return EC_OK;
+    hipMemPool_t pool = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_devs.find(t_active);
+        if (it != g_devs.end()) pool = it->second.pool;
+    }
+    if (pool) return check_hip(hipMallocFromPoolAsync(dptr, bytes, pool, S(stream)), "hipMallocFromPoolAsync");
+    return check_hip(hipMallocAsync(dptr, bytes, S(stream)), "hipMallocAsync");
+}
+extern "C" ec_status ec_free_async(void* dptr, ec_stream stream) {
+    return dptr ? check_hip(hipFreeAsync(dptr, S(stream)), "hipFreeAsync") : EC_OK;
+}
+
+// Free of a block whose last use may be on another stream than the one it is returned on: the free is ordered
+// after everything enqueued so far on `last_use_stream` (event + wait), then queued on `alloc_stream`.
+extern "C" ec_status ec_free_ordered(void* dptr, ec_stream alloc_stream, ec_stream last_use_stream) {
+    if (!dptr) return EC_OK;
+    if (alloc_stream != last_use_stream) {
+        hipEvent_t ev;
+        ec_status st = check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        if (st != EC_OK) return st;
+        st = check_hip(hipEventRecord(ev, S(last_use_stream)), "hipEventRecord");
+        if (st == EC_OK) st = check_hip(hipStreamWaitEvent(S(alloc_stream), ev, 0), "hipStreamWaitEvent");
+        (void)hipEventDestroy(ev);  // released once the wait has consumed it
+        if (st != EC_OK) return st;
+    }
+    return check_hip(hipFreeAsync(dptr, S(alloc_stream)), "hipFreeAsync");
+}
+
+extern "C" ec_status ec_pool_trim(size_t keep_bytes) {
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    hipMemPool_t pool = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_devs.find(t_active);
+        if (it != g_devs.end()) pool = it->second.pool;
+    }
+    if (!pool) return EC_OK;
+    st = check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (st != EC_OK) return st;
+    return check_hip(hipMemPoolTrimTo(pool, keep_bytes), "hipMemPoolTrimTo");
+}
+
+extern "C" ec_status ec_upload(void* dst_dev, const void* src_host, size_t bytes, ec_stream stream) {
+    if (bytes == 0) return EC_OK;
+    if (!dst_dev || !src_host) return set_error(EC_ERR_ARG, "ec_upload: null pointer");
+    ec_status st = check_hip(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, S(stream)), "hipMemcpyAsync(H2D)");
+    if (st != EC_OK) return st;
+    return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");  // src_host may be pageable
+}
+extern "C" ec_status ec_download(void* dst_host, const void* src_dev, size_t bytes, ec_stream stream) {
+    if (bytes == 0) return EC_OK;
+    if (!dst_host || !src_dev) return set_error(EC_ERR_ARG, "ec_download: null pointer");
+    ec_status st = check_hip(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync(D2H)");
+    if (st != EC_OK) return st;
+    return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+}
+extern "C" ec_status ec_copy(void* dst_dev, const void* src_dev, size_t bytes, ec_stream stream) {
+    if (bytes == 0) return EC_OK;
+    if (!dst_dev || !src_dev) return set_error(EC_ERR_ARG, "ec_copy: null pointer");
+    return check_hip(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, S(stream)), "hipMemcpyAsync(D2D)");
+}
+
+// ------------------------------------------------------------------ streams
+extern "C" ec_status ec_stream_create(ec_stream* out) {
+    if (!out) return set_error(EC_ERR_ARG, "ec_stream_create: null out");
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    hipStream_t s;
+    st = check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    if (st != EC_OK) return st;
+    *out = s;
+    return ec_prepare_stream(s);
+}
+
+extern "C" ec_status ec_prepare_stream(ec_stream stream) {
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    Scratch sc;
+    return get_scratch(S(stream), &sc);  // allocates this stream's reduction scratch now, not at first use
+}
+
+// Releases the reduction scratch the library holds for `stream` (any stream, also one it did not create).
+extern "C" ec_status ec_release_stream(ec_stream stream) {
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto dit = g_devs.find(t_active);
+    if (dit == g_devs.end()) return EC_OK;
+    auto it = dit->second.scratch.find(S(stream));
+    if (it != dit->second.scratch.end()) {
+        free_scratch(it->second.sc);
+        dit->second.scratch.erase(it);
+    }
+    return EC_OK;
+}
+
+extern "C" ec_status ec_stream_destroy(ec_stream s) {
+    ec_status st = ec_release_stream(s);
+    if (st != EC_OK) return st;
+    return check_hip(hipStreamDestroy(S(s)), "hipStreamDestroy");
+}
+extern "C" ec_status ec_stream_sync(ec_stream s) { return check_hip(hipStreamSynchronize(S(s)), "hipStreamSynchronize"); }
+
+// ------------------------------------------------------------------ tuning
+extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
+    if (!key) return set_error(EC_ERR_ARG, "ec_tune_set: null key");
+    if (!std::strcmp(key, "binop_variant")) g_tuning.binop_variant = static_cast<int>(value);
+    else if (!std::strcmp(key, "reduce_bpc")) g_tuning.reduce_bpc = value > 0 ? static_cast<int>(value) : 8;
+    else if (!std::strcmp(key, "map_u")) g_tuning.map_u = static_cast<int>(value);
+    else if (!std::strcmp(key, "peel")) g_tuning.peel = static_cast<int>(value);
+    else if (!std::strcmp(key, "unaligned_vector")) g_tuning.unaligned_vector = value != 0;
+    else if (!std::strcmp(key, "fused_mixed")) g_tuning.fused_mixed = static_cast<int>(value);
+    else if (!std::strcmp(key, "pool_keep_mb")) {
+        g_tuning.pool_keep_mb = value < 0 ? 0 : value;
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& kv : g_devs)
+            if (kv.second.pool) set_pool_threshold(kv.second.pool);
+    } else return set_error(EC_ERR_ARG, "ec_tune_set: unknown key '%s'", key);
+    return EC_OK;
+}

@@ -6,6 +6,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
+#include <string>
+
 #include "erased_cells.h"
 
 namespace ecd {
@@ -26,19 +30,26 @@ constexpr int kMaxReduceBlocks = 4096;
 
 struct Tuning;
 Tuning& tuning();
+// Process-wide knobs (ec_tune_set).  Each field is an atomic word: a knob may be turned while other host threads
+// launch — a launch sees the old or the new value of each knob, never a torn one; both are valid launch shapes.
 struct Tuning {
-    int binop_variant = 0;  // 0 = direct narrow loads, 1 = LDS-staged narrow operands
-    int reduce_bpc = 8;     // blocks per CU for reductions (partials are per block)
-    int map_u = 2;          // 16-B groups per lane per tile for the map kernels (1, 2 or 4)
-    int peel = 1;              // leading-cell peel of the binop/fused kernels: 0 off, 1 for 1-byte operands, 2 also for 2-byte ones
-    int unaligned_vector = 1;  // 1 = vector kernels at any cell offset (gfx950 unaligned global access);
-                               // 0 = pointers that are not 16-byte aligned run the cell-wise kernels
+    std::atomic<int> binop_variant{0};  // 0 = direct narrow loads, 1 = LDS-staged narrow operands
+    std::atomic<int> reduce_bpc{8};     // blocks per CU for reductions (partials are per block)
+    std::atomic<int> map_u{2};          // 16-B groups per lane per tile for the map kernels (1, 2 or 4)
+    std::atomic<int> peel{1};              // leading-cell peel of the binop/fused kernels: 0 off, 1 for 1-byte operands, 2 also for 2-byte ones
+    std::atomic<int> unaligned_vector{1};  // 1 = vector kernels at any cell offset (gfx950 unaligned global access);
+                                           // 0 = pointers that are not 16-byte aligned run the cell-wise kernels
+    std::atomic<int> fused_mixed{1};       // 1 = one-pass typed-load kernels for fused chains over mixed cell types; 0 = convert, then fuse
+    std::atomic<int64_t> pool_keep_mb{32768};  // release threshold of the library's stream-ordered pool (per device)
 };
 
-int device_cus();
+int device_cus();      // CU count of the device bound by the last ensure_ready() on this thread
+int current_device();  // that device's index
 
-ec_status ensure_ready();  // EC_ERR_NOT_INITIALIZED unless ec_init ran; binds the calling thread to the device
+ec_status ensure_ready();  // EC_ERR_NOT_INITIALIZED unless ec_init ran; binds the calling thread to its library device
 ec_status set_error(ec_status code, const char* fmt, ...);
+ec_status set_error_text(ec_status code, const std::string& text);
+const std::string& last_error_text();
 ec_status set_narrowing(int src, int dst);
 ec_status check_launch(const char* what);
 ec_status check_hip(hipError_t e, const char* what);
@@ -89,10 +100,14 @@ inline unsigned grid_capped(size_t blocks, int bpc) {
     return static_cast<unsigned>(blocks < cap ? blocks : cap);
 }
 
-// Per-stream scratch for reduction partials (device) and results (pinned host).
+// Per-(device, stream) scratch for reduction partials (device) and results (pinned host).  Launches that use the
+// partials are ordered by the stream itself; `mu` serialises the synchronous-result entry points (ec_min_max,
+// ec_mask_counts, ec_first_difference), which read `host` after waiting for the stream — two host threads sharing
+// one stream therefore take turns instead of racing on the four pinned words.
 struct Scratch {
     int64_t* dev = nullptr;    // 2*kMaxReduceBlocks partials + 4 result words
     int64_t* host = nullptr;   // 4 words, pinned
+    std::mutex* mu = nullptr;
     int64_t* dev_result() const { return dev + 2 * kMaxReduceBlocks; }
 };
 ec_status get_scratch(hipStream_t s, Scratch* out);

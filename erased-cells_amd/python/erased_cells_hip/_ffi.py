@@ -32,6 +32,16 @@ class EcValue(C.Structure):
 
 VP, SZ, I32, U8P = C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p
 PV = C.POINTER(EcValue)
+PVP, PSZ = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
+
+
+class EcCommUid(C.Structure):
+    """ec_comm_uid (ncclUniqueId): 128 opaque bytes rank 0 hands to the other ranks."""
+    _fields_ = [("bytes", C.c_char * 128)]
+
+
+# ec_shard_fn: ec_status fn(int32 shard, int32 device, ec_stream stream, void* user)
+SHARD_FN = C.CFUNCTYPE(C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p)
 
 # name -> (restype, argtypes): every symbol include/erased_cells.h declares.
 SIGNATURES = {
@@ -47,6 +57,8 @@ SIGNATURES = {
     "ec_shard_range": (I32, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ec_abi_version": (I32, []),
     "ec_init": (I32, [I32]),
+    "ec_set_device": (I32, [I32]),
+    "ec_get_device": (I32, [C.POINTER(I32)]),
     "ec_shutdown": (I32, []),
     "ec_last_error_string": (C.c_char_p, []),
     "ec_last_narrowing": (I32, [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
@@ -55,11 +67,14 @@ SIGNATURES = {
     "ec_free": (I32, [VP]),
     "ec_alloc_async": (I32, [C.POINTER(VP), SZ, VP]),
     "ec_free_async": (I32, [VP, VP]),
+    "ec_free_ordered": (I32, [VP, VP, VP]),
+    "ec_pool_trim": (I32, [SZ]),
     "ec_upload": (I32, [VP, VP, SZ, VP]),
     "ec_download": (I32, [VP, VP, SZ, VP]),
     "ec_copy": (I32, [VP, VP, SZ, VP]),
     "ec_stream_create": (I32, [C.POINTER(VP)]),
     "ec_prepare_stream": (I32, [VP]),
+    "ec_release_stream": (I32, [VP]),
     "ec_stream_destroy": (I32, [VP]),
     "ec_stream_sync": (I32, [VP]),
     "ec_binop": (I32, [I32, C.c_uint8, VP, C.c_uint8, VP, SZ, VP, VP]),
@@ -75,6 +90,23 @@ SIGNATURES = {
     "ec_min_max_decode": (I32, [C.c_uint8, C.POINTER(C.c_int64), PV, PV]),
     "ec_allreduce_min_max_keys": (I32, [VP, VP, VP]),
     "ec_allreduce_counts": (I32, [VP, VP, VP]),
+    "ec_comm_get_unique_id": (I32, [C.POINTER(EcCommUid)]),
+    "ec_comm_init_rank": (I32, [C.POINTER(EcCommUid), I32, I32, PVP]),
+    "ec_comm_init_all": (I32, [C.POINTER(I32), I32, PVP]),
+    "ec_comm_destroy": (I32, [VP]),
+    "ec_shard_group_create": (I32, [C.POINTER(I32), I32, C.c_uint32, PVP]),
+    "ec_shard_group_destroy": (I32, [VP]),
+    "ec_shard_group_size": (I32, [VP]),
+    "ec_shard_group_shard": (I32, [VP, I32, C.POINTER(I32), PVP]),
+    "ec_shard_group_foreach": (I32, [VP, SHARD_FN, VP]),
+    "ec_shard_group_sync": (I32, [VP]),
+    "ec_sharded_alloc": (I32, [VP, PSZ, PVP]),
+    "ec_sharded_free": (I32, [VP, PVP]),
+    "ec_sharded_upload": (I32, [VP, PVP, VP, PSZ, PSZ]),
+    "ec_sharded_download": (I32, [VP, VP, PVP, PSZ, PSZ]),
+    "ec_sharded_binop": (I32, [VP, I32, C.c_uint8, PVP, C.c_uint8, PVP, PSZ, PVP]),
+    "ec_sharded_min_max": (I32, [VP, C.c_uint8, PVP, PVP, PSZ, PV, PV]),
+    "ec_sharded_counts": (I32, [VP, PVP, PSZ, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ec_buffer_cmp": (I32, [C.c_uint8, VP, SZ, C.c_uint8, VP, SZ, C.POINTER(I32), VP]),
     "ec_first_difference": (I32, [C.c_uint8, VP, VP, SZ, C.POINTER(C.c_uint64), VP]),
     "ec_mask_from_nodata": (I32, [C.c_uint8, VP, SZ, PV, U8P, VP]),

@@ -289,7 +289,11 @@ class CellValue:
 class DeviceMem:
     """An HBM allocation (ec_alloc/ec_free), or a window into one (shards)."""
 
-    def __init__(self, nbytes: int, _parent: "DeviceMem" = None, _offset: int = 0):
+    _GLOBAL = object()
+
+    def __init__(self, nbytes: int, _parent: "DeviceMem" = None, _offset: int = 0, stream=_GLOBAL):
+        """`stream`: allocate (and later free) on this explicit stream — for callers that drive the ABI themselves on
+        their own stream (e.g. one stream per host thread); default: the module's current stream (set_stream)."""
         self.nbytes = nbytes
         self._parent = _parent
         if _parent is not None:
@@ -297,7 +301,9 @@ class DeviceMem:
             self._owned = False
         else:
             p = C.c_void_p()
-            check(lib().ec_alloc_async(C.byref(p), nbytes, _stream))  # stream-ordered pool: no per-op hipMalloc
+            self._explicit = stream is not DeviceMem._GLOBAL
+            self._alloc_stream = stream if self._explicit else _stream  # the block goes back to the pool on this stream
+            check(lib().ec_alloc_async(C.byref(p), nbytes, self._alloc_stream))  # stream-ordered pool: no per-op hipMalloc
             self.ptr = p.value
             self._owned = True
 
@@ -306,9 +312,13 @@ class DeviceMem:
         return DeviceMem(nbytes, _parent=self, _offset=offset)
 
     def __del__(self):
+        # The free is queued on the ALLOCATING stream, ordered (event + wait, inside ec_free_ordered) after everything
+        # enqueued so far on the stream that is current now — the stream this buffer's last operator ran on when
+        # the caller switched streams with set_stream() in between.  Freeing on "whatever stream is current" alone
+        # would let the pool hand the block out again while kernels on the other stream still use it.
         if getattr(self, "_owned", False) and self.ptr:
             try:
-                lib().ec_free_async(self.ptr, _stream)
+                lib().ec_free_ordered(self.ptr, self._alloc_stream, self._alloc_stream if self._explicit else _stream)
             except Exception:
                 pass
             self.ptr = None

@@ -7,6 +7,24 @@ pub type ec_status = i32;
 pub type ec_dtype = u8; // `CellType as u8` (src/ctype.rs:16)
 pub type ec_op = i32;
 pub type ec_stream = *mut c_void; // hipStream_t
+pub type ec_comm = *mut c_void; // ncclComm_t
+
+/// Mirrors `ec_comm_uid` (ncclUniqueId): 128 opaque bytes rank 0 hands to the other ranks.
+#[repr(C)]
+#[derive(Copy, Clone)]
+pub struct ec_comm_uid {
+    pub bytes: [c_char; 128],
+}
+
+/// Opaque `ec_shard_group`: one process driving n GPUs.
+#[repr(C)]
+pub struct ec_shard_group {
+    _private: [u8; 0],
+}
+pub const EC_GROUP_RCCL: u32 = 0;
+pub const EC_GROUP_HOST_COMBINE: u32 = 1;
+/// `ec_shard_fn`: called once per shard on that shard's launch thread.
+pub type ec_shard_fn = extern "C" fn(shard: i32, device: i32, stream: ec_stream, user: *mut c_void) -> ec_status;
 
 pub const EC_OK: ec_status = 0;
 pub const EC_ERR_NARROWING: ec_status = 1;
@@ -27,6 +45,8 @@ pub struct ec_value {
 extern "C" {
     pub fn ec_abi_version() -> i32;
     pub fn ec_init(device: i32) -> ec_status;
+    pub fn ec_set_device(device: i32) -> ec_status;
+    pub fn ec_get_device(device: *mut i32) -> ec_status;
     pub fn ec_shutdown() -> ec_status;
     pub fn ec_last_error_string() -> *const c_char;
     pub fn ec_last_narrowing(src: *mut ec_dtype, dst: *mut ec_dtype) -> ec_status;
@@ -36,8 +56,11 @@ extern "C" {
     pub fn ec_free(dptr: *mut c_void) -> ec_status;
     pub fn ec_alloc_async(dptr: *mut *mut c_void, bytes: usize, s: ec_stream) -> ec_status;
     pub fn ec_free_async(dptr: *mut c_void, s: ec_stream) -> ec_status;
+    pub fn ec_free_ordered(dptr: *mut c_void, alloc_stream: ec_stream, last_use_stream: ec_stream) -> ec_status;
+    pub fn ec_pool_trim(keep_bytes: usize) -> ec_status;
     pub fn ec_stream_create(out: *mut ec_stream) -> ec_status;
     pub fn ec_prepare_stream(s: ec_stream) -> ec_status;
+    pub fn ec_release_stream(s: ec_stream) -> ec_status;
     pub fn ec_stream_destroy(s: ec_stream) -> ec_status;
     pub fn ec_stream_sync(s: ec_stream) -> ec_status;
     pub fn ec_upload(dst_dev: *mut c_void, src_host: *const c_void, bytes: usize, s: ec_stream) -> ec_status;
@@ -89,8 +112,32 @@ extern "C" {
     pub fn ec_masked_fused(o1: ec_op, o2: ec_op, o3: ec_op, dt: *const ec_dtype, p: *const *const c_void,
                            masks: *const *const u8, scalars_or_null: *const ec_value, n: usize, out: *mut f64,
                            out_mask: *mut u8, s: ec_stream) -> ec_status;
-    pub fn ec_allreduce_min_max_keys(rccl_comm: *mut c_void, keys2_dev: *mut i64, s: ec_stream) -> ec_status;
-    pub fn ec_allreduce_counts(rccl_comm: *mut c_void, counts2_dev: *mut u64, s: ec_stream) -> ec_status;
+    pub fn ec_comm_get_unique_id(uid: *mut ec_comm_uid) -> ec_status;
+    pub fn ec_comm_init_rank(uid: *const ec_comm_uid, n_ranks: i32, rank: i32, comm: *mut ec_comm) -> ec_status;
+    pub fn ec_comm_init_all(devices: *const i32, n: i32, comms: *mut ec_comm) -> ec_status;
+    pub fn ec_comm_destroy(comm: ec_comm) -> ec_status;
+    pub fn ec_allreduce_min_max_keys(comm: ec_comm, keys2_dev: *mut i64, s: ec_stream) -> ec_status;
+    pub fn ec_allreduce_counts(comm: ec_comm, counts2_dev: *mut u64, s: ec_stream) -> ec_status;
+
+    pub fn ec_shard_group_create(devices: *const i32, n: i32, flags: u32, out: *mut *mut ec_shard_group) -> ec_status;
+    pub fn ec_shard_group_destroy(g: *mut ec_shard_group) -> ec_status;
+    pub fn ec_shard_group_size(g: *const ec_shard_group) -> i32;
+    pub fn ec_shard_group_shard(g: *const ec_shard_group, shard: i32, device: *mut i32, stream: *mut ec_stream) -> ec_status;
+    pub fn ec_shard_group_foreach(g: *mut ec_shard_group, f: ec_shard_fn, user: *mut c_void) -> ec_status;
+    pub fn ec_shard_group_sync(g: *mut ec_shard_group) -> ec_status;
+    pub fn ec_sharded_alloc(g: *mut ec_shard_group, bytes: *const usize, dptrs: *mut *mut c_void) -> ec_status;
+    pub fn ec_sharded_free(g: *mut ec_shard_group, dptrs: *const *mut c_void) -> ec_status;
+    pub fn ec_sharded_upload(g: *mut ec_shard_group, dst_dev: *const *mut c_void, src_host: *const c_void,
+                             byte_offsets: *const usize, bytes: *const usize) -> ec_status;
+    pub fn ec_sharded_download(g: *mut ec_shard_group, dst_host: *mut c_void, src_dev: *const *const c_void,
+                               byte_offsets: *const usize, bytes: *const usize) -> ec_status;
+    pub fn ec_sharded_binop(g: *mut ec_shard_group, op: ec_op, lt: ec_dtype, l: *const *const c_void, rt: ec_dtype,
+                            r: *const *const c_void, n: *const usize, out: *const *mut f64) -> ec_status;
+    pub fn ec_sharded_min_max(g: *mut ec_shard_group, t: ec_dtype, p: *const *const c_void,
+                              masks_or_null: *const *const u8, n: *const usize, mn: *mut ec_value,
+                              mx: *mut ec_value) -> ec_status;
+    pub fn ec_sharded_counts(g: *mut ec_shard_group, masks: *const *const u8, n: *const usize, n_true: *mut u64,
+                             n_false: *mut u64) -> ec_status;
     pub fn ec_shard_range(n_rows: u64, n_cols: u64, shard: u32, n_shards: u32, cell_offset: *mut u64,
                           cell_len: *mut u64) -> ec_status;
 

@@ -99,9 +99,16 @@ ec_status ec_shard_range(uint64_t n_rows, uint64_t n_cols, uint32_t shard, uint3
  * Runtime: device, memory, streams, errors.
  * ---------------------------------------------------------------- */
 int32_t ec_abi_version(void);
-ec_status ec_init(int32_t device);   /* binds the process to `device` (one process per GPU); idempotent for the
-                                        same device, EC_ERR_ARG for another one until ec_shutdown() */
-ec_status ec_shutdown(void);         /* frees reduction scratch */
+/* The runtime is per device.  ec_init(device) sets up `device` (its CU count, a stream-ordered memory pool the
+ * library owns, per-stream reduction scratch) and makes it the calling thread's current library device; it may be
+ * called for several devices (one process driving all GPUs of a node) and is idempotent.  Host threads that never
+ * chose a device use the first one the process initialised — the one-process-per-GPU shape needs nothing else.
+ * ec_set_device switches the calling thread between initialised devices: allocations, streams and launches of a
+ * thread go to its current library device.  Device pointers and streams must be used with their own device. */
+ec_status ec_init(int32_t device);
+ec_status ec_set_device(int32_t device);
+ec_status ec_get_device(int32_t *device);
+ec_status ec_shutdown(void);         /* waits for every initialised device, frees scratch, trims and destroys the pools */
 const char *ec_last_error_string(void);
 /* src/dst of the last EC_ERR_NARROWING on this thread (Error::NarrowingError fields). */
 ec_status ec_last_narrowing(ec_dtype *src, ec_dtype *dst);
@@ -114,17 +121,28 @@ ec_status ec_free(void *dptr);
  * src/buffer.rs:327).  A block may be used by work enqueued on `stream` after the call, and freed
  * blocks are recycled without synchronising the device. */
 ec_status ec_alloc_async(void **dptr, size_t bytes, ec_stream stream);
+/* `stream` must be ordered after the last use of the block (the stream that used it last, normally). */
 ec_status ec_free_async(void *dptr, ec_stream stream);
+/* Free of a block allocated on `alloc_stream` whose last use was enqueued on `last_use_stream`: the free is queued on
+ * `alloc_stream` after an event recorded on `last_use_stream` — what a host mirror's destructor calls, which cannot
+ * know on which stream the caller works by the time a buffer is dropped. */
+ec_status ec_free_ordered(void *dptr, ec_stream alloc_stream, ec_stream last_use_stream);
+/* The pool caches freed blocks up to its release threshold (ec_tune_set("pool_keep_mb"), default 32768 per
+ * device); ec_pool_trim waits for the current device and returns everything above `keep_bytes` to the driver. */
+ec_status ec_pool_trim(size_t keep_bytes);
 ec_status ec_upload(void *dst_dev, const void *src_host, size_t bytes, ec_stream stream);   /* From<Vec<T>> */
 ec_status ec_download(void *dst_host, const void *src_dev, size_t bytes, ec_stream stream); /* to_vec; waits for completion */
 ec_status ec_copy(void *dst_dev, const void *src_dev, size_t bytes, ec_stream stream);      /* Clone (buffer.rs:151-153) */
 ec_status ec_stream_create(ec_stream *out);
 /* Allocates the per-stream reduction scratch of a stream the library did not create (NULL = default
  * stream, a torch stream, ...).  After this, every asynchronous entry point — including ec_min_max_keys and
- * ec_mask_counts_device — performs no allocation and no synchronisation (ec_fused over mixed cell types
- * excepted: it draws temporaries from the stream-ordered pool), so a chain of calls can be captured into a
+ * ec_mask_counts_device — performs no allocation and no synchronisation (ec_fused over combinations of cell types
+ * without a one-pass kernel excepted: it draws temporaries from the stream-ordered pool), so a chain of calls can be captured into a
  * hipGraph on that stream and replayed. */
 ec_status ec_prepare_stream(ec_stream stream);
+/* Releases that scratch again (the library holds scratch for at most 64 streams per device and recycles the
+ * least recently used entry beyond that, so calling this for a dying foreign stream is optional). */
+ec_status ec_release_stream(ec_stream stream);
 ec_status ec_stream_destroy(ec_stream s);
 ec_status ec_stream_sync(ec_stream s);
 
@@ -188,13 +206,64 @@ ec_status ec_min_max_keys(ec_dtype t, const void *p, const uint8_t *mask_or_null
                           int64_t *keys2_dev, ec_stream stream);
 ec_status ec_min_max_decode(ec_dtype t, const int64_t keys2_host[2], ec_value *mn, ec_value *mx);
 
-/* The sharded path's only exchange, for hosts that own an RCCL communicator (`ncclComm_t`, one rank per
- * GPU): in-place all-reduce over xGMI of the 16-byte device payloads written by
- * ec_min_max_keys (MAX over two int64) and ec_mask_counts_device (SUM over two uint64).  Asynchronous on
- * `stream`.  librccl is loaded lazily; EC_ERR_RCCL if it is missing or the collective fails.
+/* ---------------------------------------------------------------- *
+ * The sharded path: a raster is cut into contiguous row-blocks (ec_shard_range), one per GPU;
+ * element-wise kernels are local to a shard, and the only exchange is the all-reduce over xGMI of the
+ * 16-byte reduction payloads written by ec_min_max_keys (MAX over two int64) and ec_mask_counts_device
+ * (SUM over two uint64).  The reference has no counterpart (it is single-threaded CPU code); what is
+ * reduced is BufferOps::min_max (src/buffer.rs:169-173) and Mask::counts (src/masked/mask.rs:72-80).
+ * ---------------------------------------------------------------- */
+typedef void *ec_comm; /* ncclComm_t; librccl is loaded lazily, EC_ERR_RCCL if it is missing or a call fails */
+typedef struct ec_comm_uid { char bytes[128]; } ec_comm_uid; /* ncclUniqueId */
+/* One process per GPU: rank 0 makes the id, the host program hands its 128 bytes to the other ranks (a file, a
+ * socket, MPI, ...), every rank calls ec_comm_init_rank with its current library device bound (blocks until all
+ * n_ranks have joined). */
+ec_status ec_comm_get_unique_id(ec_comm_uid *uid);
+ec_status ec_comm_init_rank(const ec_comm_uid *uid, int32_t n_ranks, int32_t rank, ec_comm *comm);
+/* One process, n GPUs: ec_init()s every listed device and builds the clique (ncclCommInitAll). */
+ec_status ec_comm_init_all(const int32_t *devices, int32_t n, ec_comm *comms);
+ec_status ec_comm_destroy(ec_comm comm);
+/* In-place all-reduce of the device payloads; asynchronous on `stream` (the stream the payload was produced on).
  * (bench.py and the Python mirror use torch.distributed's all_reduce, which is the same RCCL call.) */
-ec_status ec_allreduce_min_max_keys(void *rccl_comm, int64_t *keys2_dev, ec_stream stream);
-ec_status ec_allreduce_counts(void *rccl_comm, uint64_t *counts2_dev, ec_stream stream);
+ec_status ec_allreduce_min_max_keys(ec_comm comm, int64_t *keys2_dev, ec_stream stream);
+ec_status ec_allreduce_counts(ec_comm comm, uint64_t *counts2_dev, ec_stream stream);
+
+/* A shard group: one process driving n GPUs — per device a launch thread bound to it, a stream, a 32-byte payload
+ * slot and (unless EC_GROUP_HOST_COMBINE) an RCCL communicator of the n-device clique.  Shard i of every sharded
+ * call lives on device i of the group.  The per-device threads issue their launches concurrently, so a fan-out
+ * costs one launch latency, not n.  EC_GROUP_HOST_COMBINE folds the n 16-byte payloads on the host instead of
+ * over xGMI (no RCCL needed; also the only way to list one device twice, e.g. to rehearse on a 1-GPU box). */
+typedef struct ec_shard_group ec_shard_group;
+enum { EC_GROUP_RCCL = 0, EC_GROUP_HOST_COMBINE = 1 };
+ec_status ec_shard_group_create(const int32_t *devices, int32_t n, uint32_t flags, ec_shard_group **out);
+ec_status ec_shard_group_destroy(ec_shard_group *g);
+int32_t ec_shard_group_size(const ec_shard_group *g);
+ec_status ec_shard_group_shard(const ec_shard_group *g, int32_t shard, int32_t *device, ec_stream *stream);
+/* Runs fn(shard, device, stream, user) once per shard, each on that shard's launch thread with its device current,
+ * concurrently; returns when all have returned (the work they enqueued may still be running): the building block
+ * with which a host fans out any entry point of this header.  The first failing status is returned. */
+typedef ec_status (*ec_shard_fn)(int32_t shard, int32_t device, ec_stream stream, void *user);
+ec_status ec_shard_group_foreach(ec_shard_group *g, ec_shard_fn fn, void *user);
+ec_status ec_shard_group_sync(ec_shard_group *g); /* waits for every shard's stream */
+/* Per-shard device blocks (bytes[i] on device i) and the scatter / gather of one host buffer by byte ranges
+ * (`From<Vec<T>>` / `to_vec` of a sharded buffer; the ranges come from ec_shard_range x sizeof(T)). */
+ec_status ec_sharded_alloc(ec_shard_group *g, const size_t *bytes, void **dptrs);
+ec_status ec_sharded_free(ec_shard_group *g, void *const *dptrs);
+ec_status ec_sharded_upload(ec_shard_group *g, void *const *dst_dev, const void *src_host,
+                            const size_t *byte_offsets, const size_t *bytes);
+ec_status ec_sharded_download(ec_shard_group *g, void *dst_host, const void *const *src_dev,
+                              const size_t *byte_offsets, const size_t *bytes);
+/* impl {Add,Sub,Mul,Div} for &CellBuffer (src/buffer.rs:324-329) on every shard; asynchronous, no communication. */
+ec_status ec_sharded_binop(ec_shard_group *g, ec_op op, ec_dtype lt, const void *const *l, ec_dtype rt,
+                           const void *const *r, const size_t *n, double *const *out);
+/* BufferOps::min_max (src/buffer.rs:169-173; masked: src/masked/masked_buffer.rs:208-217) of the whole raster:
+ * ec_min_max_keys per shard, one all-reduce(MAX) of the 16-byte keys, decode.  masks_or_null == NULL: unmasked.
+ * Synchronous result. */
+ec_status ec_sharded_min_max(ec_shard_group *g, ec_dtype t, const void *const *p, const uint8_t *const *masks_or_null,
+                             const size_t *n, ec_value *mn, ec_value *mx);
+/* Mask::counts (src/masked/mask.rs:72-80) of the whole raster: per-shard counts, all-reduce(SUM). Synchronous result. */
+ec_status ec_sharded_counts(ec_shard_group *g, const uint8_t *const *masks, const size_t *n,
+                            uint64_t *n_true, uint64_t *n_false);
 
 /* ---------------------------------------------------------------- *
  * Ordering / equality of whole buffers, decided on the device (no download of the cells).
@@ -237,7 +306,9 @@ ec_status ec_synth_fill(ec_dtype t, void *dst, size_t n, uint64_t seed, uint64_t
                         double lo, double hi, ec_stream stream);
 /* mask[i] = splitmix64(seed ^ (base+i)) % 100 >= pct_nodata */
 ec_status ec_synth_mask(uint8_t *dst, size_t n, uint64_t seed, uint64_t base, uint32_t pct_nodata, ec_stream stream);
-/* Tuning knobs: "binop_variant" (0 direct narrow loads, 1 LDS-staged), "reduce_bpc" (workgroups per CU for reductions),
+/* Tuning knobs (each an atomic word: may be set while other host threads launch): "pool_keep_mb" (release threshold
+ * of the library's stream-ordered pools), "fused_mixed" (1, default: one-pass kernels for fused chains over mixed
+ * cell types; 0: convert to the union type first), "binop_variant" (0 direct narrow loads, 1 LDS-staged), "reduce_bpc" (workgroups per CU for reductions),
  * "map_u" (16-B groups per lane per tile of the map kernels: 1, 2 or 4), "unaligned_vector" (1, default: vector
  * kernels at any cell offset via unaligned global access; 0: pointers that are not 16-byte aligned run the
  * one-cell-per-lane kernels), "peel" (leading-cell peel of the binop/fused kernels at odd offsets: 0 off, 1 for

@@ -24,6 +24,7 @@ def ec():
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "erased_cells.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"typedef[^;{]*\(\*[^;]*;", "", text)  # function-pointer typedefs (ec_shard_fn) are not entry points
     return sorted(set(re.findall(r"\b(ec_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -162,6 +163,7 @@ def test_rust_extern_block_declares_every_entry_point():
     symbols, same number of arguments each."""
     import re
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "erased_cells.h")).read(), flags=re.S)
+    hdr = re.sub(r"typedef[^;{]*\(\*[^;]*;", "", hdr)
     c_decls = {m.group(1): m.group(2) for m in re.finditer(r"\b(ec_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)}
     rs = re.sub(r"//.*", "", open(os.path.join(ROOT, "erased-cells_amd", "rust", "erased-cells-hip", "src", "ffi.rs")).read())
     r_decls = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (ec_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->[^;]*)?;", rs, flags=re.S)}

@@ -34,6 +34,8 @@ def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
                  ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
         assert isinstance(d[k], t), k
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["vs_baseline"] is None
+    assert d["verified"] is True and d["cpu_baseline"]["oracle_check_of_timed_output"] is True
+    assert d["roofline"]["traffic"] is None or "recorded profiles/traffic.json" in d["roofline"]["traffic_source"]
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - d["config"]["cells"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
     rf = d["roofline"]

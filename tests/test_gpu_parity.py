@@ -251,6 +251,23 @@ def test_mask_logic_and_counts(ec, ua):
     assert m.len() == 1000
     assert np.array_equal(m.to_numpy(), np.concatenate([a[:600] & b, a[600:]]))
     assert ec.Mask.new(a).shard(7, 500).counts() == eco.mask_counts(a[7:507])  # unaligned window
+    # in-place (owned) forms on ragged windows at odd offsets: out aliases lhs (mask.rs:103-109,118-127,142-151)
+    import ctypes as C
+    L = ec.lib()
+    for n, off in ((70001, 3), (4099, 1), (33, 13)):
+        a, b = rand_mask(n + off, 85), rand_mask(n + off, 86, 0.5)
+        for name, fn in (("and", eco.mask_and), ("or", eco.mask_or)):
+            whole, rhs = ec.Mask.new(a), ec.Mask.new(b)
+            w, r = whole.shard(off, n), rhs.shard(off, n)
+            if name == "and":
+                w &= r
+            else:
+                w |= r
+            assert np.array_equal(whole.to_numpy(), np.concatenate([a[:off], fn(a[off:], b[off:])])), (name, n, off)
+        whole = ec.Mask.new(a)
+        w = whole.shard(off, n)
+        ec._ffi.check(L.ec_mask_not(w.mem.ptr, n, w.mem.ptr, ec.stream()))  # Not for Mask, in place
+        assert np.array_equal(whole.to_numpy(), np.concatenate([a[:off], eco.mask_not(a[off:])]))
 
 
 # ---------------------------------------------------------------- masked binop: src/masked/masked_buffer.rs:326-335
@@ -528,8 +545,9 @@ def test_streams_threads_and_graph_capture(ec):
         ec._ffi.check(L.ec_stream_create(C.byref(s)))
         try:
             a, b = inputs[i]
-            da, db = ec.DeviceMem(a.nbytes), ec.DeviceMem(b.nbytes)
-            out, keys = ec.DeviceMem(n * 8), ec.DeviceMem(16)
+            # pooled blocks are allocated on the stream that uses them (stream-ordered allocation)
+            da, db = ec.DeviceMem(a.nbytes, stream=s), ec.DeviceMem(b.nbytes, stream=s)
+            out, keys = ec.DeviceMem(n * 8, stream=s), ec.DeviceMem(16, stream=s)
             ec._ffi.check(L.ec_upload(da.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes, s))
             ec._ffi.check(L.ec_upload(db.ptr, b.ctypes.data_as(C.c_void_p), b.nbytes, s))
             k = np.empty(2, np.int64)
@@ -538,6 +556,7 @@ def test_streams_threads_and_graph_capture(ec):
                 ec._ffi.check(L.ec_min_max_keys(ec.Float64, out.ptr, None, n, keys.ptr, s))
             ec._ffi.check(L.ec_download(k.ctypes.data_as(C.c_void_p), keys.ptr, 16, s))
             results[i] = (int(k[0]), int(k[1]))
+            del da, db, out, keys  # back to the pool on `s`, before the stream goes away
         finally:
             ec._ffi.check(L.ec_stream_destroy(s))
 

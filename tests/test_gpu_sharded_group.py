@@ -1,0 +1,259 @@
+"""The in-process sharded path and the runtime around it, through the C ABI.
+
+`examples/sharded.c` is a plain C program (no torch, no Python) that drives an ec_shard_group: row-block
+scatter, per-shard divide, RCCL all-reduce of the min/max keys and of the counts.  A 1-GPU box can run it
+with one device over RCCL (a 1-rank clique) and with the same device listed several times under
+EC_GROUP_HOST_COMBINE (the fan-out threads, shard ranges and the combine are all exercised; only the xGMI
+hop is not).  Every number it prints is recomputed here with the oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import eco
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "erased-cells_amd")
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "sharded_c")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "sharded.c"), "-L" + LIBDIR, "-lerased_cells_hip",
+                        "-Wl,-rpath," + LIBDIR, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_sharded_example_is_plain_c99_and_links():
+    import tempfile
+    import pathlib
+    with tempfile.TemporaryDirectory() as d:
+        _build(pathlib.Path(d))
+
+
+def _expected(rows, cols, n_shards):
+    cells = rows * cols
+    k = np.arange(cells, dtype=np.uint64)
+    x = (((k * np.uint64(2654435761)) >> np.uint64(13)) & np.uint64(0xFFFF)).astype(np.uint16)
+    x[(x == 0) | (x == 65535)] = 1
+    d = (np.uint64(1) + (k * np.uint64(40503)) % np.uint64(65535)).astype(np.uint16)
+    q, rem = divmod(rows, n_shards)
+    lens = [(q + (1 if g < rem else 0)) * cols for g in range(n_shards)]
+    x[cells - 1 - lens[-1] // 2] = 0
+    x[lens[0] // 2] = 65535
+    mn, mx = eco.min_max(x)
+    qq = eco.f_binop(eco.DIV, x, d)
+    qmn, qmx = eco.f_min_max(qq)
+    m = eco.mask_from_nodata(x, eco.ND_VALUE, eco.Value.of(eco.U16, 7))
+    data, nodata = eco.mask_counts(m)
+    return f"min {int(mn.get())} max {int(mx.get())} qmin {qmn.bits()} qmax {qmx.bits()} data {data} nodata {nodata}"
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("devices,host_combine", [(["0"], 0), (["0"], 1), (["0", "0"], 1), (["0", "0", "0", "0", "0"], 1)])
+def test_sharded_path_from_plain_c(tmp_path, devices, host_combine):
+    rows, cols = 1031, 997  # rows not divisible by the shard counts: ragged row-blocks
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([_build(tmp_path), str(rows), str(cols), str(host_combine)] + devices, capture_output=True, text=True,
+                       timeout=500, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("min ")]
+    assert lines == [_expected(rows, cols, len(devices))], r.stdout
+
+
+@pytest.mark.gpu
+def test_duplicate_device_needs_host_combine(tmp_path):
+    r = subprocess.run([_build(tmp_path), "64", "64", "0", "0", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "listed twice" in r.stderr
+
+
+@pytest.fixture(scope="module")
+def ec():
+    import erased_cells_hip as ec
+    ec.init(0)
+    return ec
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_comm_bootstrap_through_the_abi(ec):
+    """ec_comm_get_unique_id / ec_comm_init_rank / ec_comm_init_all / ec_comm_destroy: communicators made by the
+    library itself (1 rank is what one GPU allows) carry the reduction payloads unchanged."""
+    from erased_cells_hip import sharded
+    from vectors import rand_cells, rand_mask
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    L, chk = ec.lib(), ec._ffi.check
+    a, m = rand_cells(eco.I32, 300007, 11), rand_mask(300007, 12)
+    d, dm = ec.CellBuffer.from_vec(a), ec.Mask.new(m)
+    uid, comm = ec._ffi.EcCommUid(), C.c_void_p()
+    chk(L.ec_comm_get_unique_id(C.byref(uid)))
+    chk(L.ec_comm_init_rank(C.byref(uid), 1, 0, C.byref(comm)))
+    comms = (C.c_void_p * 1)()
+    chk(L.ec_comm_init_all((C.c_int32 * 1)(0), 1, comms))
+    try:
+        for cm in (comm, C.c_void_p(comms[0])):
+            keys, counts = ec.DeviceMem(16), ec.DeviceMem(16)
+            chk(L.ec_min_max_keys(ec.Int32, d.mem.ptr, dm.mem.ptr, d.len(), keys.ptr, None))
+            chk(L.ec_allreduce_min_max_keys(cm, keys.ptr, None))
+            chk(L.ec_mask_counts_device(dm.mem.ptr, dm.len(), counts.ptr, None))
+            chk(L.ec_allreduce_counts(cm, counts.ptr, None))
+            k, c = np.empty(2, np.int64), np.empty(2, np.uint64)
+            chk(L.ec_download(k.ctypes.data_as(C.c_void_p), keys.ptr, 16, None))
+            chk(L.ec_download(c.ctypes.data_as(C.c_void_p), counts.ptr, 16, None))
+            mn, mx = sharded.combine_min_max_keys(ec.Int32, (int(k[0]), int(k[1])))
+            emn, emx = eco.f_min_max(a, m)
+            assert (mn.bits(), mx.bits()) == (emn.bits(), emx.bits())
+            assert (int(c[0]), int(c[1])) == eco.mask_counts(m)
+        assert L.ec_comm_init_rank(C.byref(uid), 1, 1, C.byref(C.c_void_p())) == ec._ffi.EC_ERR_ARG
+        assert L.ec_comm_init_all((C.c_int32 * 2)(0, 0), 2, (C.c_void_p * 2)()) == ec._ffi.EC_ERR_ARG
+    finally:
+        chk(L.ec_comm_destroy(comm))
+        chk(L.ec_comm_destroy(comms[0]))
+
+
+@pytest.mark.gpu
+def test_shard_group_from_python_matches_oracle(ec):
+    """The same group API through ctypes: 3 shards (one device, host combine) of a masked f32 raster; an empty shard
+    (more shards than rows) contributes the idempotent sentinels."""
+    from erased_cells_hip import sharded
+    from vectors import rand_cells, rand_mask
+    L, chk = ec.lib(), ec._ffi.check
+    for rows, cols, G in ((50, 401, 3), (2, 17, 4)):
+        a, m = rand_cells(eco.F32, rows * cols, 21), rand_mask(rows * cols, 22)
+        grp = C.c_void_p()
+        chk(L.ec_shard_group_create((C.c_int32 * G)(*([0] * G)), G, 1, C.byref(grp)))
+        try:
+            assert L.ec_shard_group_size(grp) == G
+            rng = [sharded.shard_range(rows, cols, g, G) for g in range(G)]
+            n = (C.c_size_t * G)(*[r[1] for r in rng])
+            b4, b1 = (C.c_size_t * G)(*[r[1] * 4 for r in rng]), (C.c_size_t * G)(*[r[1] for r in rng])
+            o4, o1 = (C.c_size_t * G)(*[r[0] * 4 for r in rng]), (C.c_size_t * G)(*[r[0] for r in rng])
+            da, dm = (C.c_void_p * G)(), (C.c_void_p * G)()
+            chk(L.ec_sharded_alloc(grp, b4, da))
+            chk(L.ec_sharded_alloc(grp, b1, dm))
+            chk(L.ec_sharded_upload(grp, da, a.ctypes.data_as(C.c_void_p), o4, b4))
+            chk(L.ec_sharded_upload(grp, dm, m.ctypes.data_as(C.c_void_p), o1, b1))
+            mn, mx = ec._ffi.EcValue(), ec._ffi.EcValue()
+            chk(L.ec_sharded_min_max(grp, ec.Float32, da, dm, n, C.byref(mn), C.byref(mx)))
+            emn, emx = eco.f_min_max(a, m)
+            assert (ec.CellValue.from_ec(mn).bits(), ec.CellValue.from_ec(mx).bits()) == (emn.bits(), emx.bits())
+            t, f = C.c_uint64(), C.c_uint64()
+            chk(L.ec_sharded_counts(grp, dm, n, C.byref(t), C.byref(f)))
+            assert (t.value, f.value) == eco.mask_counts(m)
+            back = np.empty_like(a)
+            chk(L.ec_sharded_download(grp, back.ctypes.data_as(C.c_void_p), da, o4, b4))
+            assert np.array_equal(back.view(np.uint32), a.view(np.uint32))
+            dev, st = C.c_int32(-1), C.c_void_p()
+            chk(L.ec_shard_group_shard(grp, G - 1, C.byref(dev), C.byref(st)))
+            assert dev.value == 0 and st.value
+            assert L.ec_shard_group_shard(grp, G, None, None) == ec._ffi.EC_ERR_ARG
+            chk(L.ec_shard_group_sync(grp))
+            chk(L.ec_sharded_free(grp, da))
+            chk(L.ec_sharded_free(grp, dm))
+        finally:
+            chk(L.ec_shard_group_destroy(grp))
+
+
+@pytest.mark.gpu
+def test_device_selection_and_pool(ec):
+    L, chk = ec.lib(), ec._ffi.check
+    dev = C.c_int32(-1)
+    chk(L.ec_get_device(C.byref(dev)))
+    assert dev.value == 0
+    chk(L.ec_set_device(0))
+    import torch
+    bad = torch.cuda.device_count()  # first index that does not exist
+    assert L.ec_set_device(bad) == ec._ffi.EC_ERR_NOT_INITIALIZED
+    assert L.ec_init(bad) == ec._ffi.EC_ERR_ARG
+    # pooled blocks: allocate on one stream, last use on another, free ordered behind that use
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    chk(L.ec_stream_create(C.byref(s1)))
+    chk(L.ec_stream_create(C.byref(s2)))
+    n = 1 << 22
+    a = np.arange(n, dtype=np.uint16)
+    src = ec.CellBuffer.from_vec(a)
+    for _ in range(8):
+        p, q = C.c_void_p(), C.c_void_p()
+        chk(L.ec_alloc_async(C.byref(p), 4 * n, s1))
+        chk(L.ec_stream_sync(s1))
+        chk(L.ec_convert(ec.UInt16, src.mem.ptr, ec.Float32, p, n, s2))   # last use on s2
+        chk(L.ec_free_ordered(p, s1, s2))                                   # returned on s1, behind s2's kernel
+        chk(L.ec_alloc_async(C.byref(q), 4 * n, s1))                        # may be the same block again
+        chk(L.ec_convert(ec.UInt16, src.mem.ptr, ec.Int32, q, n, s1))
+        got = np.empty(n, np.int32)
+        chk(L.ec_download(got.ctypes.data_as(C.c_void_p), q, 4 * n, s1))
+        assert np.array_equal(got, a.astype(np.int32))
+        chk(L.ec_free_async(q, s1))
+    chk(L.ec_stream_sync(s2))
+    chk(L.ec_pool_trim(0))
+    chk(L.ec_tune_set(b"pool_keep_mb", 1024))
+    chk(L.ec_tune_set(b"pool_keep_mb", 32768))
+    chk(L.ec_stream_destroy(s1))
+    chk(L.ec_stream_destroy(s2))
+
+
+@pytest.mark.gpu
+def test_scratch_table_is_bounded_and_streams_can_be_released(ec):
+    """More streams than the library keeps scratch for (64 per device): the least recently used entries are recycled
+    and every stream still gets the right answer, also when it comes back after its entry was dropped."""
+    from vectors import rand_cells
+    L, chk = ec.lib(), ec._ffi.check
+    a = rand_cells(eco.I16, 70001, 31)
+    d = ec.CellBuffer.from_vec(a)
+    emn, emx = eco.f_min_max(a)
+    streams = []
+    for _ in range(80):
+        s = C.c_void_p()
+        chk(L.ec_stream_create(C.byref(s)))
+        streams.append(s)
+    for rnd in range(2):
+        for s in streams:
+            mn, mx = ec._ffi.EcValue(), ec._ffi.EcValue()
+            chk(L.ec_min_max(ec.Int16, d.mem.ptr, None, d.len(), C.byref(mn), C.byref(mx), s))
+            assert (ec.CellValue.from_ec(mn).bits(), ec.CellValue.from_ec(mx).bits()) == (emn.bits(), emx.bits())
+    chk(L.ec_release_stream(streams[0]))
+    chk(L.ec_release_stream(streams[0]))  # idempotent
+    for s in streams:
+        chk(L.ec_stream_destroy(s))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_host_threads_sharing_one_stream_take_turns(ec):
+    """Synchronous-result entry points on ONE stream from several host threads: the per-stream pinned result words
+    are guarded, so each thread reads its own answer."""
+    from vectors import rand_cells, rand_mask
+    L, chk = ec.lib(), ec._ffi.check
+    s = C.c_void_p()
+    chk(L.ec_stream_create(C.byref(s)))
+    cases = []
+    for i in range(4):
+        a = rand_cells(eco.U16, 50000 + 977 * i, 41 + i)
+        m = rand_mask(a.size, 51 + i)
+        cases.append((ec.CellBuffer.from_vec(a), ec.Mask.new(m), eco.f_min_max(a), eco.mask_counts(m)))
+    errors = []
+
+    def work(i):
+        try:
+            buf, msk, (emn, emx), ecnt = cases[i]
+            for _ in range(200):
+                mn, mx = ec._ffi.EcValue(), ec._ffi.EcValue()
+                chk(L.ec_min_max(ec.UInt16, buf.mem.ptr, None, buf.len(), C.byref(mn), C.byref(mx), s))
+                assert (ec.CellValue.from_ec(mn).bits(), ec.CellValue.from_ec(mx).bits()) == (emn.bits(), emx.bits())
+                t, f = C.c_uint64(), C.c_uint64()
+                chk(L.ec_mask_counts(msk.mem.ptr, msk.len(), C.byref(t), C.byref(f), s))
+                assert (t.value, f.value) == ecnt
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:3]
+    chk(L.ec_stream_destroy(s))
