@@ -1,17 +1,75 @@
-// ec_fused.hip — ABI entry points of the fused two-level expression kernels (ec_fused_kernels.hpp):
-// operand set-up (aliases, scalars, masks), unification of mixed operand types, dispatch by op triple.
+// ec_fused.hip — ABI entry points of the fused two-level expression kernels (ec_fused_kernels.hpp, ec_fused_mixed.hpp):
+// operand set-up (aliases, scalars, masks), dispatch by op triple; operands of two cell types run the per-slot typed
+// one-pass kernel where one is instantiated, other mixes are unified (converted) first.
 #include <hip/hip_runtime.h>
 
-#include "ec_fused_kernels.hpp"
+#include "ec_fused_mixed.hpp"
 #include "ec_lattice.hpp"
 #include "ec_runtime.hpp"
 
 namespace ecd {
 template <int O2>
 void dispatch_fused(const FusedArgs& fa, int same_dt, unsigned grid, double* out, uint8_t* out_mask, size_t n, hipStream_t s);
+template <int O2>
+bool dispatch_fused_mixed(const FusedArgs& fa, int pair, int pat, unsigned grid, double* out, uint8_t* om, size_t n, hipStream_t s);
 }
 
 using namespace ecd;
+
+// Buffer operands of exactly two cell types: the one-pass kernel with per-slot typed loads (ec_fused_mixed.hpp), if
+// one is instantiated for this (ordered type pair, slot pattern).  Returns true when it was launched.
+static bool try_fused_mixed(FusedArgs& fa, int nops, size_t n, double* out, uint8_t* out_mask, hipStream_t s) {
+    int types[2] = {-1, -1}, nt = 0;
+    for (int k = 0; k < nops; ++k) {
+        if (fa.is_sc[k]) continue;
+        const int t = fa.dt[k];
+        if (nt > 0 && t == types[0]) continue;
+        if (nt > 1 && t == types[1]) continue;
+        if (nt == 2) return false;  // three cell types
+        types[nt++] = t;
+    }
+    if (nt != 2) return false;
+    static const int kPairs[kFusedMixedPairs][2] = {
+#define EC_ROW(IDX, AID, AT, BID, BT) {AID, BID},
+        EC_FUSED_MIXED_PAIRS(EC_ROW)
+#undef EC_ROW
+    };
+    static const int kPats4[] = {kPatABAB};
+    static const int kPats3[] = {kPatAAB, kPatABA, kPatABB};
+    const int* pats = nops == 4 ? kPats4 : kPats3;
+    const int npats = nops == 4 ? 1 : 3;
+    for (int order = 0; order < 2; ++order) {
+        const int A = types[order], B = types[1 - order];
+        int pair = -1;
+        for (int i = 0; i < kFusedMixedPairs; ++i)
+            if (kPairs[i][0] == A && kPairs[i][1] == B) pair = i;
+        if (pair < 0) continue;
+        for (int pi = 0; pi < npats; ++pi) {
+            const int pat = pats[pi];
+            bool fits = true;
+            for (int k = 0; k < nops && fits; ++k)
+                if (!fa.is_sc[k]) fits = (fa.dt[k] == B) == (((pat >> k) & 1) != 0);  // a scalar fits any slot
+            if (!fits) continue;
+            // peel one leading cell when that puts more of the 1-byte operands on even addresses (peel_head's rule)
+            unsigned c0 = 0, c1 = 0;
+            for (int k = 0; k < nops; ++k)
+                if (!fa.is_sc[k] && fa.alias[k] == k) {
+                    c0 += peel_cost(fa.p[k], ecl::size_of(fa.dt[k]), 0);
+                    c1 += peel_cost(fa.p[k], ecl::size_of(fa.dt[k]), 1);
+                }
+            fa.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
+            const size_t per_tile = size_t(kBlock) * kFusedU;
+            const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
+            switch (fa.o2) {
+                case EC_ADD: return dispatch_fused_mixed<EC_ADD>(fa, pair, pat, grid, out, out_mask, n, s);
+                case EC_SUB: return dispatch_fused_mixed<EC_SUB>(fa, pair, pat, grid, out, out_mask, n, s);
+                case EC_MUL: return dispatch_fused_mixed<EC_MUL>(fa, pair, pat, grid, out, out_mask, n, s);
+                default: return dispatch_fused_mixed<EC_DIV>(fa, pair, pat, grid, out, out_mask, n, s);
+            }
+        }
+    }
+    return false;
+}
 
 static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], const void* const p[4],
                               const uint8_t* const masks[4], const ec_value* scalars, size_t n, double* out,
@@ -64,7 +122,9 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         k_fused_cellwise<0><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fa, out, out_mask, n);
         return check_launch("fused(cellwise)");
     }
-    // Mixed operand types: widen every buffer operand to the common CellType::union first (the
+    if (tuning().fused_mixed && try_fused_mixed(fa, nops, n, out, out_mask, s)) return check_launch("fused(mixed)");
+    fa.head = 0;
+    // Other mixes of operand types: widen every buffer operand to the common CellType::union first (the
     // reference's `unify`, value-preserving — SURVEY App. A.1) into temporaries from the stream-ordered
     // pool, then run the same-type kernel.  Same-type calls allocate nothing.
     int u = fa.dt[first_buf];

@@ -83,6 +83,7 @@ static std::map<int, DeviceState> g_devs;
 static std::atomic<int> g_default_device{-1};
 static std::atomic<uint64_t> g_generation{1};  // bumped by ec_shutdown: invalidates every thread's cached binding
 static std::atomic<uint64_t> g_stamp{0};
+static std::atomic<int64_t> g_pool_allocs{0};  // ec_alloc_async calls that reached the pool (ec_stat_get)
 static Tuning g_tuning;
 
 static thread_local int t_device = -1;          // this thread's choice (ec_init / ec_set_device), -1 = process default
@@ -294,6 +295,7 @@ extern "C" ec_status ec_alloc_async(void** dptr, size_t bytes, ec_stream stream)
         auto it = g_devs.find(t_active);
         if (it != g_devs.end()) pool = it->second.pool;
     }
+    g_pool_allocs.fetch_add(1, std::memory_order_relaxed);
     if (pool) return check_hip(hipMallocFromPoolAsync(dptr, bytes, pool, S(stream)), "hipMallocFromPoolAsync");
     return check_hip(hipMallocAsync(dptr, bytes, S(stream)), "hipMallocAsync");
 }
@@ -392,6 +394,22 @@ extern "C" ec_status ec_stream_destroy(ec_stream s) {
     return check_hip(hipStreamDestroy(S(s)), "hipStreamDestroy");
 }
 extern "C" ec_status ec_stream_sync(ec_stream s) { return check_hip(hipStreamSynchronize(S(s)), "hipStreamSynchronize"); }
+
+// ------------------------------------------------------------------ statistics
+extern "C" ec_status ec_stat_get(const char* key, int64_t* value) {
+    if (!key || !value) return set_error(EC_ERR_ARG, "ec_stat_get: null argument");
+    if (!std::strcmp(key, "pool_allocs")) *value = g_pool_allocs.load(std::memory_order_relaxed);
+    else if (!std::strcmp(key, "devices")) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        *value = static_cast<int64_t>(g_devs.size());
+    } else if (!std::strcmp(key, "scratch_streams")) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        int64_t n = 0;
+        for (auto& kv : g_devs) n += static_cast<int64_t>(kv.second.scratch.size());
+        *value = n;
+    } else return set_error(EC_ERR_ARG, "ec_stat_get: unknown key '%s'", key);
+    return EC_OK;
+}
 
 // ------------------------------------------------------------------ tuning
 extern "C" ec_status ec_tune_set(const char* key, int64_t value) {

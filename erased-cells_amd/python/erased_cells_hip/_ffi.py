@@ -119,6 +119,7 @@ SIGNATURES = {
     "ec_synth_fill": (I32, [C.c_uint8, VP, SZ, C.c_uint64, C.c_uint64, C.c_double, C.c_double, VP]),
     "ec_synth_mask": (I32, [U8P, SZ, C.c_uint64, C.c_uint64, C.c_uint32, VP]),
     "ec_tune_set": (I32, [C.c_char_p, C.c_int64]),
+    "ec_stat_get": (I32, [C.c_char_p, C.POINTER(C.c_int64)]),
 }
 
 

@@ -146,4 +146,5 @@ extern "C" {
                          s: ec_stream) -> ec_status;
     pub fn ec_synth_mask(dst: *mut u8, n: usize, seed: u64, base: u64, pct_nodata: u32, s: ec_stream) -> ec_status;
     pub fn ec_tune_set(key: *const c_char, value: i64) -> ec_status;
+    pub fn ec_stat_get(key: *const c_char, value: *mut i64) -> ec_status;
 }

@@ -314,6 +314,10 @@ ec_status ec_synth_mask(uint8_t *dst, size_t n, uint64_t seed, uint64_t base, ui
  * one-cell-per-lane kernels), "peel" (leading-cell peel of the binop/fused kernels at odd offsets: 0 off, 1 for
  * 1-byte operands (default), 2 also for 2-byte operands). */
 ec_status ec_tune_set(const char *key, int64_t value);
+/* Counters for tests: "pool_allocs" (ec_alloc_async calls so far, including those the library makes itself — a call
+ * that leaves it unchanged allocated nothing), "devices" (initialised devices), "scratch_streams" (streams the
+ * library currently holds reduction scratch for). */
+ec_status ec_stat_get(const char *key, int64_t *value);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import eco
-from vectors import assert_f64_bits_equal, bits_of, rand_cells, rand_mask
+from vectors import assert_f64_bits_equal, bits_of, chain_loose, rand_cells, rand_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -87,11 +87,22 @@ def test_masked_binop_direct_every_pair(ec, pool):
                 assert np.array_equal(got.mask().to_numpy(), m[0][:N] & m[1][:N])
 
 
+def _oracle_chain(o1, hx, hy, o2, hz, o3=None, hw=None):
+    """The eager chain on the oracle's typed loops + the cells whose NaN bits the reference leaves open."""
+    e1 = eco.f_binop(o1, hx, hy)
+    e2 = eco.f_binop(o3, hz, hw) if o3 is not None else hz
+    eo = eco.f_binop(o2, e1, e2)
+    return eo, chain_loose(o1, hx, hy, o2, e1, e2, o3, hz if o3 is not None else None, hw)
+
+
 @pytest.mark.parametrize("ct", range(NT))
 def test_fused_every_op_triple(ec, pool, ct):
-    """All 80 (o1, o2, o3) instantiations of k_fused_same<T> for each cell type: bit-identical to the eager chain."""
+    """All 80 (o1, o2, o3) instantiations of k_fused_same<T> for each cell type: bit-identical to the eager HIP chain,
+    and to the ORACLE's chain under the same rule as test_binop_all_pairs_bit_exact (NaNs bit for bit, except cells
+    where both operands of a commutative step are NaN)."""
     host, dev, _, _ = pool
     x, y = dev[ct].shard(0, N), dev[ct].shard(4, N)
+    hx, hy = host[ct][:N], host[ct][4:4 + N]
     for o1 in OPS:
         t1 = x._binop(o1, y)
         for o2 in OPS:
@@ -99,10 +110,88 @@ def test_fused_every_op_triple(ec, pool, ct):
                 if o3 == ec.fused.OP_NONE:
                     got = ec.fused.expr(x, o1, y, o2, y)
                     exp = t1._binop(o2, y)
+                    eo, loose = _oracle_chain(o1, hx, hy, o2, hy)
                 else:
                     got = ec.fused.expr(x, o1, y, o2, y, o3, x)
                     exp = t1._binop(o2, y._binop(o3, x))
-                assert np.array_equal(bits_of(got.to_numpy()), bits_of(exp.to_numpy())), (ct, o1, o2, o3)
+                    eo, loose = _oracle_chain(o1, hx, hy, o2, hy, o3, hx)
+                g = got.to_numpy()
+                assert np.array_equal(bits_of(g), bits_of(exp.to_numpy())), (ct, o1, o2, o3)
+                assert_f64_bits_equal(g, eo, nan_by_class_where=loose)
+
+
+MIXED_PAIRS = [(eco.U16, eco.F32), (eco.F32, eco.U16), (eco.U8, eco.U16), (eco.U16, eco.U8),
+               (eco.I16, eco.F32), (eco.F32, eco.I16), (eco.F32, eco.F64), (eco.F64, eco.F32)]
+
+
+def _pool_allocs(ec):
+    v = C.c_int64()
+    ec._ffi.check(ec.lib().ec_stat_get(b"pool_allocs", C.byref(v)))
+    return v.value
+
+
+@pytest.mark.parametrize("pair", MIXED_PAIRS, ids=lambda p: f"{eco.CT_NAMES[p[0]]}-{eco.CT_NAMES[p[1]]}")
+def test_fused_mixed_every_instantiation(ec, pool, pair):
+    """All 28 x 4 k_fused_mixed<A,B,pattern,o1,o2,o3> kernels of each ordered type pair (A B A B with every op triple;
+    A A B, A B A, A B B with every op pair): against the oracle's chain (strict NaN rule), against the eager HIP
+    chain, against the convert-then-fuse path — and the one-pass path must not allocate."""
+    host, dev, _, _ = pool
+    A, B = pair
+    L = ec.lib()
+    a0, a1, b0, b1 = dev[A].shard(0, N), dev[A].shard(3, N), dev[B].shard(1, N), dev[B].shard(5, N)
+    ha0, ha1, hb0, hb1 = host[A][:N], host[A][3:3 + N], host[B][1:1 + N], host[B][5:5 + N]
+    out = ec.CellBuffer.empty(N, ec.Float64)  # result buffer made up front: only the kernel's own allocations would count
+
+    def run(ops, o1, o2, o3):
+        dt = (C.c_uint8 * 4)(*[o.ct for o in ops], *([0] * (4 - len(ops))))
+        p = (C.c_void_p * 4)(*[o.mem.ptr for o in ops], *([None] * (4 - len(ops))))
+        ec._ffi.check(L.ec_fused(o1, o2, o3, dt, p, None, N, out.mem.ptr, ec.stream()))
+        return out.to_numpy()
+
+    cases = [((a0, b0, a0, b0), (ha0, hb0, ha0, hb0)),   # A B A B, NDVI-shaped aliases
+             ((a0, b0, a1, b1), (ha0, hb0, ha1, hb1))]   # A B A B, four distinct streams
+    for o1 in OPS:
+        for o2 in OPS:
+            for o3 in OPS:
+                for ops, h in cases[: 1 if (o1 + o2 + o3) % 2 else 2]:
+                    before = _pool_allocs(ec)
+                    g = run(ops, o1, o2, o3)
+                    assert _pool_allocs(ec) == before, "the one-pass mixed kernel must not allocate"
+                    eo, loose = _oracle_chain(o1, h[0], h[1], o2, h[2], o3, h[3])
+                    assert_f64_bits_equal(g, eo, nan_by_class_where=loose)
+            for ops, h in (((a0, a1, b0), (ha0, ha1, hb0)), ((a0, b0, a1), (ha0, hb0, ha1)), ((a0, b0, b1), (ha0, hb0, hb1)),
+                           ((a0, b0, b0), (ha0, hb0, hb0))):
+                before = _pool_allocs(ec)
+                g = run(ops, o1, o2, ec.fused.OP_NONE)
+                assert _pool_allocs(ec) == before
+                eo, loose = _oracle_chain(o1, h[0], h[1], o2, h[2])
+                assert_f64_bits_equal(g, eo, nan_by_class_where=loose)
+    # the same calls through convert-then-fuse and through the eager chain give the same bits
+    try:
+        for (o1, o2, o3) in ((eco.SUB, eco.DIV, eco.ADD), (eco.MUL, eco.SUB, eco.DIV), (eco.ADD, eco.MUL, ec.fused.OP_NONE)):
+            ops = (a0, b0, a1, b1) if o3 != ec.fused.OP_NONE else (a0, a1, b0)
+            L.ec_tune_set(b"fused_mixed", 1)
+            g1 = run(ops, o1, o2, o3).copy()
+            L.ec_tune_set(b"fused_mixed", 0)
+            before = _pool_allocs(ec)
+            g0 = run(ops, o1, o2, o3).copy()
+            assert _pool_allocs(ec) > before  # the fallback does draw temporaries
+            t1 = ops[0]._binop(o1, ops[1])
+            eager = t1._binop(o2, ops[2]._binop(o3, ops[3]) if o3 != ec.fused.OP_NONE else ops[2]).to_numpy()
+            assert np.array_equal(bits_of(g1), bits_of(g0)) and np.array_equal(bits_of(g1), bits_of(eager))
+    finally:
+        L.ec_tune_set(b"fused_mixed", 1)
+    # scalars fit any slot; masks ride along; windows at odd offsets and ragged lengths
+    for n, off in ((1, 0), (2, 1), (513, 1), (2049, 3)):
+        x, y = dev[A].shard(off, n), dev[B].shard(off + 1, n)
+        hx, hy = host[A][off:off + n], host[B][off + 1:off + 1 + n]
+        got = ec.fused.expr(x, eco.SUB, y, eco.DIV, x, eco.ADD, 2.5).to_numpy()   # A B A s
+        assert np.array_equal(bits_of(got), bits_of(((x - y) / (x + 2.5)).to_numpy()))
+        got = ec.fused.expr(x, eco.MUL, 3, eco.ADD, y).to_numpy()                  # A s B
+        assert np.array_equal(bits_of(got), bits_of(((x * 3) + y).to_numpy()))
+        got = ec.fused.ndvi(x, y).to_numpy()
+        eo, loose = _oracle_chain(eco.SUB, hx, hy, eco.DIV, hx, eco.ADD, hy)
+        assert_f64_bits_equal(got, eo, nan_by_class_where=loose)
 
 
 @pytest.mark.parametrize("map_u,vector,off", [(1, 1, 0), (2, 1, 0), (4, 1, 0), (2, 0, 1)],

@@ -65,3 +65,21 @@ def assert_f64_bits_equal(got: np.ndarray, exp: np.ndarray, nan_by_class_where=N
         i = int(np.flatnonzero(bad)[0])
         raise AssertionError(f"{int(bad.sum())} cells differ; first at {i}: got {got[i]!r} ({int(g[i]):#x}) "
                              f"expected {exp[i]!r} ({int(e[i]):#x})")
+
+
+def both_nan(l: np.ndarray, r: np.ndarray) -> np.ndarray:
+    with np.errstate(all="ignore"):
+        return np.isnan(np.asarray(l).astype(np.float64)) & np.isnan(np.asarray(r).astype(np.float64))
+
+
+def chain_loose(o1, x, y, o2, e1, e2, o3=None, z=None, w=None) -> np.ndarray:
+    """Cells of `(x o1 y) o2 (z o3 w)` whose NaN sign/payload the reference does not pin — the single-op rule
+    (both operands NaN under a commutative op: x86 returns whichever operand the compiler put first), carried
+    through the chain: a step is loose where its own operands are both NaN under Add/Mul, or where an input of it
+    was already loose (its payload is what propagates).  Everything else, NaNs included, must match bit for bit."""
+    comm = (0, 2)  # ADD, MUL
+    loose1 = both_nan(x, y) if o1 in comm else np.zeros(len(e1), bool)
+    loose3 = (both_nan(z, w) if o3 in comm else np.zeros(len(e1), bool)) if o3 is not None else np.zeros(len(e1), bool)
+    loose2 = both_nan(e1, e2) if o2 in comm else np.zeros(len(e1), bool)
+    n = len(e1)
+    return loose1[:n] | loose3[:n] | loose2
