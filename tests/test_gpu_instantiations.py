@@ -257,13 +257,47 @@ SMALL = {  # cell type -> (lowest, highest) cell value
 }
 
 
+class _OracleOnDevice:
+    """Expected cells computed by the CPU oracle (all host cores) into a page-locked buffer, copied to the GPU and
+    compared there with ec_buffer_cmp — so that billions of cells can be checked against the ORACLE (not against
+    another HIP kernel) without downloading results."""
+
+    def __init__(self, ec, cap):
+        import os
+        import torch
+        self.ec, self.torch = ec, torch
+        self.host = torch.empty(cap, dtype=torch.float64).pin_memory()
+        self.dev = torch.empty(cap, dtype=torch.float64, device="cuda")
+        self.cores = min(64, len(os.sched_getaffinity(0)))
+        eco.set_threads(self.cores)
+
+    def close(self):
+        eco.set_threads(0)
+
+    def expect_buffer(self, n):
+        return self.host.numpy()[:n]
+
+    def check(self, got_ptr, n, what):
+        self.dev[:n].copy_(self.host[:n], non_blocking=False)
+        order = C.c_int32(7)
+        self.ec._ffi.check(self.ec.lib().ec_buffer_cmp(self.ec.Float64, got_ptr, n, self.ec.Float64, self.dev.data_ptr(), n,
+                                                      C.byref(order), None))
+        if order.value != 0:
+            idx = C.c_uint64()
+            self.ec._ffi.check(self.ec.lib().ec_first_difference(self.ec.Float64, got_ptr, self.dev.data_ptr(), n, C.byref(idx), None))
+            raise AssertionError(f"{what}: first cell that differs from the oracle: {idx.value}")
+
+
+@pytest.mark.timeout(1800)
 @pytest.mark.parametrize("lname", list(SMALL))
 @pytest.mark.parametrize("rname", list(SMALL))
 def test_small_integer_divide_is_exact_for_every_operand_pair(ec, lname, rname):
     """The divide of two cells of at most 16 bits uses a 6-instruction sequence (ec_device.hpp div_small_int) instead
-    of the IEEE expansion.  Its operand space is small enough to try EVERY pair: each (a, b) of the two cell types
-    goes through ec_binop (short sequence) and, widened to f64 first, through the f64 ÷ f64 kernel (IEEE expansion,
-    the path the oracle pins on all other tests); the two results must agree bit for bit on the device."""
+    of the IEEE expansion.  Its operand space is small enough to try EVERY pair against the CPU ORACLE: for each of
+    the 16 type pairs every (a, b) goes through ec_binop on the GPU, the oracle's typed loop (`(a as f64) / (b as
+    f64)`, x86 divsd — src/value.rs:207) computes the same cells on the host, and the two are compared bit for bit on
+    the device.  The four 16-bit pairs alone are 4 x 2^32 cells; together the pairs cover all 98304^2 operand values,
+    zeros in the divisor (±inf, NaN with the x86 sign) included."""
     import torch
     L = ec.lib()
     chk = ec._ffi.check
@@ -272,40 +306,45 @@ def test_small_integer_divide_is_exact_for_every_operand_pair(ec, lname, rname):
     (llo, lhi), (rlo, rhi) = SMALL[lname], SMALL[rname]
     na, nb = lhi - llo + 1, rhi - rlo + 1
     a_vals = torch.arange(llo, lhi + 1, dtype=torch.int32, device="cuda")
+    ha_vals = np.arange(llo, lhi + 1).astype(ec.NP_DTYPES[lt])
     rows = max(1, min(nb, (1 << 27) // na))  # b-values per chunk: at most 2^27 cells at a time
-    for b0 in range(rlo, rhi + 1, rows):
-        nb_c = min(rows, rhi + 1 - b0)
-        n = na * nb_c
-        a = a_vals.repeat(nb_c).to(tdt[lname])
-        b = torch.arange(b0, b0 + nb_c, dtype=torch.int32, device="cuda").repeat_interleave(na).to(tdt[rname])
-        fast = torch.empty(n, dtype=torch.float64, device="cuda")
-        a64, b64, ref = torch.empty_like(fast), torch.empty_like(fast), torch.empty_like(fast)
-        torch.cuda.synchronize()
-        chk(L.ec_binop(ec.DIV, lt, a.data_ptr(), rt, b.data_ptr(), n, fast.data_ptr(), None))
-        chk(L.ec_convert(lt, a.data_ptr(), ec.Float64, a64.data_ptr(), n, None))
-        chk(L.ec_convert(rt, b.data_ptr(), ec.Float64, b64.data_ptr(), n, None))
-        chk(L.ec_binop(ec.DIV, ec.Float64, a64.data_ptr(), ec.Float64, b64.data_ptr(), n, ref.data_ptr(), None))
-        order = C.c_int32(7)
-        chk(L.ec_buffer_cmp(ec.Float64, fast.data_ptr(), n, ec.Float64, ref.data_ptr(), n, C.byref(order), None))
-        assert order.value == 0, (lname, rname, b0)
-    # and a slice against the CPU oracle, zeros in the divisor included
-    l = np.arange(llo, lhi + 1).astype(ec.NP_DTYPES[lt])
+    orc = _OracleOnDevice(ec, na * rows)
+    try:
+        for b0 in range(rlo, rhi + 1, rows):
+            nb_c = min(rows, rhi + 1 - b0)
+            n = na * nb_c
+            a = a_vals.repeat(nb_c).to(tdt[lname])
+            b = torch.arange(b0, b0 + nb_c, dtype=torch.int32, device="cuda").repeat_interleave(na).to(tdt[rname])
+            fast = torch.empty(n, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            chk(L.ec_binop(ec.DIV, lt, a.data_ptr(), rt, b.data_ptr(), n, fast.data_ptr(), None))
+            ha = np.tile(ha_vals, nb_c)
+            hb = np.repeat(np.arange(b0, b0 + nb_c).astype(ec.NP_DTYPES[rt]), na)
+            eco.f_binop(eco.DIV, ha, hb, orc.expect_buffer(n))
+            orc.check(fast.data_ptr(), n, f"{lname} / {rname}, divisors from {b0}")
+    finally:
+        orc.close()
+    # the reference-shaped form of the oracle agrees on a slice too (zeros in the divisor included)
+    l = np.arange(llo, lhi + 1).astype(ec.NP_DTYPES[lt])[:4096]
     for bv in (0, 1, rlo, rhi, 3, 7):
         r = np.full(l.size, bv).astype(ec.NP_DTYPES[rt])
         got = (ec.CellBuffer.from_vec(l) / ec.CellBuffer.from_vec(r)).to_numpy()
-        assert_f64_bits_equal(got, eco.f_binop(eco.DIV, l, r))
+        assert_f64_bits_equal(got, eco.binop(eco.DIV, l, r))
 
 
+@pytest.mark.timeout(3000)
 @pytest.mark.parametrize("tname", ["UInt16", "Int16"])
 def test_fused_ndvi_small_integer_divide_is_exact_for_every_numerator_and_denominator(ec, tname):
     """`(x - y) / (z + w)` on 16-bit cells runs as 2 adds + the 6-instruction divide (ec_fused_kernels.hpp).  Every
-    (numerator, denominator) such cells can produce is enumerated — 131071² pairs — and the fused kernel is compared on
-    the device with the eager chain (three launches, IEEE divide of the f64 temporaries)."""
+    (numerator, denominator) such cells can produce is enumerated — 131071² pairs — and the fused kernel is compared
+    with the ORACLE's eager chain (`f_binop` Sub, Add, then Div of the f64 temporaries: three x86 steps per cell,
+    as src/gdal/rasterband.rs:148 evaluates it), bit for bit, on the device."""
     import torch
     L = ec.lib()
     chk = ec._ffi.check
     ct = getattr(ec, tname)
     tdt = {"UInt16": torch.uint16, "Int16": torch.int16}[tname]
+    npdt = ec.NP_DTYPES[ct]
     lo, hi = SMALL[tname]
     t1_lo, t1_hi, t2_lo, t2_hi = lo - hi, hi - lo, 2 * lo, 2 * hi
     n1 = t1_hi - t1_lo + 1
@@ -316,24 +355,29 @@ def test_fused_ndvi_small_integer_divide_is_exact_for_every_numerator_and_denomi
         x1 = torch.div(t1, 2, rounding_mode="floor")
         y1 = x1 - t1
     assert int(x1.min()) >= lo and int(x1.max()) <= hi and int(y1.min()) >= lo and int(y1.max()) <= hi
+    hx1, hy1 = x1.cpu().numpy().astype(npdt), y1.cpu().numpy().astype(npdt)
     rows = max(1, (1 << 27) // n1)
     dt4 = (C.c_uint8 * 4)(ct, ct, ct, ct)
-    for b0 in range(t2_lo, t2_hi + 1, rows):
-        nb = min(rows, t2_hi + 1 - b0)
-        n = n1 * nb
-        t2 = torch.arange(b0, b0 + nb, dtype=torch.int32, device="cuda")
-        z1 = torch.div(t2, 2, rounding_mode="floor")
-        w1 = t2 - z1
-        x, y = x1.repeat(nb).to(tdt), y1.repeat(nb).to(tdt)
-        z, w = z1.repeat_interleave(n1).to(tdt), w1.repeat_interleave(n1).to(tdt)
-        fused = torch.empty(n, dtype=torch.float64, device="cuda")
-        num, den, ref = torch.empty_like(fused), torch.empty_like(fused), torch.empty_like(fused)
-        torch.cuda.synchronize()
-        p4 = (C.c_void_p * 4)(x.data_ptr(), y.data_ptr(), z.data_ptr(), w.data_ptr())
-        chk(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, None, n, fused.data_ptr(), None))
-        chk(L.ec_binop(ec.SUB, ct, x.data_ptr(), ct, y.data_ptr(), n, num.data_ptr(), None))
-        chk(L.ec_binop(ec.ADD, ct, z.data_ptr(), ct, w.data_ptr(), n, den.data_ptr(), None))
-        chk(L.ec_binop(ec.DIV, ec.Float64, num.data_ptr(), ec.Float64, den.data_ptr(), n, ref.data_ptr(), None))
-        order = C.c_int32(7)
-        chk(L.ec_buffer_cmp(ec.Float64, fused.data_ptr(), n, ec.Float64, ref.data_ptr(), n, C.byref(order), None))
-        assert order.value == 0, (tname, b0)
+    orc = _OracleOnDevice(ec, n1 * rows)
+    e1, e2 = np.empty(n1 * rows, np.float64), np.empty(n1 * rows, np.float64)
+    try:
+        for b0 in range(t2_lo, t2_hi + 1, rows):
+            nb = min(rows, t2_hi + 1 - b0)
+            n = n1 * nb
+            t2 = torch.arange(b0, b0 + nb, dtype=torch.int32, device="cuda")
+            z1 = torch.div(t2, 2, rounding_mode="floor")
+            w1 = t2 - z1
+            x, y = x1.repeat(nb).to(tdt), y1.repeat(nb).to(tdt)
+            z, w = z1.repeat_interleave(n1).to(tdt), w1.repeat_interleave(n1).to(tdt)
+            fused = torch.empty(n, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            p4 = (C.c_void_p * 4)(x.data_ptr(), y.data_ptr(), z.data_ptr(), w.data_ptr())
+            chk(L.ec_fused(ec.SUB, ec.DIV, ec.ADD, dt4, p4, None, n, fused.data_ptr(), None))
+            hz1 = z1.cpu().numpy().astype(npdt)
+            hw1 = w1.cpu().numpy().astype(npdt)
+            eco.f_binop(eco.SUB, np.tile(hx1, nb), np.tile(hy1, nb), e1[:n])
+            eco.f_binop(eco.ADD, np.repeat(hz1, n1), np.repeat(hw1, n1), e2[:n])
+            eco.f_binop(eco.DIV, e1[:n], e2[:n], orc.expect_buffer(n))
+            orc.check(fused.data_ptr(), n, f"fused NDVI {tname}, denominators from {b0}")
+    finally:
+        orc.close()
