@@ -98,11 +98,13 @@ static ec_status launch_min_max(const void* p, const uint8_t* mask, size_t n, in
         if (al) {
             const unsigned head = reduce_head(p, sizeof(T), n);
             const size_t groups = (n - head) / (16 / sizeof(T));
-            size_t tiles = (groups + size_t(kBlock) * kReduceU - 1) / (size_t(kBlock) * kReduceU);
+            size_t tiles = (groups + size_t(kRBlock) * kReduceU - 1) / (size_t(kRBlock) * kReduceU);
             if (tiles < 1) tiles = 1;
             grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
-            if (mask) k_min_max_partials<T, true, kReduceU><<<grid, kBlock, 0, s>>>(tp, mask, n, sc.dev, head);
-            else k_min_max_partials<T, false, kReduceU><<<grid, kBlock, 0, s>>>(tp, nullptr, n, sc.dev, head);
+            int64_t* direct = grid == 1 ? keys2_dev : nullptr;  // one workgroup: it writes the result itself
+            if (mask) k_min_max_partials<T, true, kReduceU><<<grid, kRBlock, 0, s>>>(tp, mask, n, sc.dev, head, direct);
+            else k_min_max_partials<T, false, kReduceU><<<grid, kRBlock, 0, s>>>(tp, nullptr, n, sc.dev, head, direct);
+            if (direct) return check_launch("min_max(single workgroup)");
         } else {
             size_t blocks = (n + kBlock - 1) / kBlock;
             grid = static_cast<unsigned>(blocks < size_t(cap) ? blocks : size_t(cap));
@@ -368,10 +370,10 @@ static ec_status first_diff_w(const void* l, const void* r, size_t n, const Scra
     if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
     const bool al = aligned16(l, r, r);
     const unsigned head = al ? reduce_head(l, sizeof(W), n) : 0u;
-    size_t tiles = al ? ((n - head) / (16 / sizeof(W)) + size_t(kBlock) * kReduceU - 1) / (size_t(kBlock) * kReduceU) : (n + kBlock - 1) / kBlock;
+    size_t tiles = al ? ((n - head) / (16 / sizeof(W)) + size_t(kRBlock) * kReduceU - 1) / (size_t(kRBlock) * kReduceU) : (n + kRBlock - 1) / kRBlock;
     if (tiles < 1) tiles = 1;
     const unsigned grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
-    k_first_diff_partials<W, kReduceU><<<grid, kBlock, 0, s>>>(static_cast<const W*>(l), static_cast<const W*>(r), n,
+    k_first_diff_partials<W, kReduceU><<<grid, kRBlock, 0, s>>>(static_cast<const W*>(l), static_cast<const W*>(r), n,
                                                                reinterpret_cast<uint64_t*>(sc.dev), al, head);
     *grid_out = grid;
     return check_launch("first_diff(partials)");
@@ -525,12 +527,13 @@ extern "C" ec_status ec_mask_counts_device(const uint8_t* m, size_t n, uint64_t*
         if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
         const bool al = aligned_to(m, 16);
         const unsigned head = al ? reduce_head(m, 1, n) : 0u;
-        size_t tiles = al ? ((n - head) / 16 + size_t(kBlock) * kReduceU - 1) / (size_t(kBlock) * kReduceU) : (n + kBlock - 1) / kBlock;
+        size_t tiles = al ? ((n - head) / 16 + size_t(kRBlock) * kReduceU - 1) / (size_t(kRBlock) * kReduceU) : (n + kRBlock - 1) / kRBlock;
         if (tiles < 1) tiles = 1;
         grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
-        k_mask_count_partials<kReduceU><<<grid, kBlock, 0, S(stream)>>>(m, n, reinterpret_cast<uint64_t*>(sc.dev), al, head);
+        uint64_t* direct = grid == 1 ? counts2_dev : nullptr;  // one workgroup: it writes the result itself
+        k_mask_count_partials<kReduceU><<<grid, kRBlock, 0, S(stream)>>>(m, n, reinterpret_cast<uint64_t*>(sc.dev), al, head, direct);
         st = check_launch("mask_counts(partials)");
-        if (st != EC_OK) return st;
+        if (st != EC_OK || direct) return st;
     }
     k_mask_count_finalize<<<1, kFinalizeBlock, 0, S(stream)>>>(reinterpret_cast<const uint64_t*>(sc.dev), static_cast<int>(grid), n, counts2_dev);
     return check_launch("mask_counts(finalize)");

@@ -120,10 +120,20 @@ struct ByteFold {
     }
 };
 
+// Launch shape of the reductions (tools/tune_reduce.hip, profiles/r02/tune_reduce.log): 512-thread workgroups with
+// 8 x 16 B in flight per lane and a grid capped at 4 workgroups per CU read a 16384² byte mask in 41.4 µs including
+// the finalize launch (0.81 of 8 TB/s); round 1's 256 threads x 4 loads x 8/CU took 43.3 µs, one tile per workgroup
+// 42.4, and single-launch forms (write-through partials + relaxed ticket, the last workgroup folds) 41.6 at best.
+constexpr int kRBlock = 512;
+constexpr int kRWaves = kRBlock / kWave;
+
 // partials[2*b] = min key, partials[2*b+1] = max key of block b (int64 order keys).
 template <typename T, bool MASKED, int U>
-__global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict__ p, const uint8_t* __restrict__ mask,
-                                                             size_t n, int64_t* __restrict__ partials, unsigned head) {
+__global__ __launch_bounds__(kRBlock) void k_min_max_partials(const T* __restrict__ p, const uint8_t* __restrict__ mask,
+                                                             size_t n, int64_t* __restrict__ partials, unsigned head,
+                                                             int64_t* __restrict__ keys2_if_single) {
+    // keys2_if_single != nullptr (only with a one-workgroup grid): this workgroup's fold IS the result, so it writes
+    // {~key(min), key(max)} itself and the finalize launch is skipped — half the latency for small buffers.
     // `head` leading cells (reduce_head(), ec_runtime.hpp) are folded one by one by workgroup 0 so that the
     // 16-byte loads of the rest start 16-byte aligned: a window at an odd u16 offset otherwise reads 27 % slower
     p += head;
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict
     bf.init();
 
     const size_t ngroups = n / CPL;
-    constexpr size_t TILE = size_t(kBlock) * U;
+    constexpr size_t TILE = size_t(kRBlock) * U;
     const size_t ntiles = (ngroups + TILE - 1) / TILE;
     const TV* __restrict__ pv = reinterpret_cast<const TV*>(p);
     const MV* __restrict__ mv = reinterpret_cast<const MV*>(mask);
@@ -175,15 +185,15 @@ __global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict
             MV m[U] = {};
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                x[j] = nt_load(pv + base + size_t(j) * kBlock);
-                if constexpr (MASKED) m[j] = nt_load(mv + base + size_t(j) * kBlock);
+                x[j] = nt_load(pv + base + size_t(j) * kRBlock);
+                if constexpr (MASKED) m[j] = nt_load(mv + base + size_t(j) * kRBlock);
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) fold(x[j], m[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                const size_t g = base + size_t(j) * kBlock;
+                const size_t g = base + size_t(j) * kRBlock;
                 if (g < ngroups) {
                     MV m = {};
                     if constexpr (MASKED) m = plain_load(mv + g);
@@ -211,23 +221,28 @@ __global__ __launch_bounds__(kBlock) void k_min_max_partials(const T* __restrict
             amin = key < amin ? key : amin;
             amax = key > amax ? key : amax;
         };
-        for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kBlock) fold_cell(static_cast<ptrdiff_t>(i));
-        for (unsigned h = threadIdx.x; h < head; h += kBlock) fold_cell(-static_cast<ptrdiff_t>(h) - 1);  // the peeled cells
+        for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kRBlock) fold_cell(static_cast<ptrdiff_t>(i));
+        for (unsigned h = threadIdx.x; h < head; h += kRBlock) fold_cell(-static_cast<ptrdiff_t>(h) - 1);  // the peeled cells
     }
     int64_t kmin = wave_min_i64(acc_to_i64<A>(amin));
     int64_t kmax = wave_max_i64(acc_to_i64<A>(amax));
-    __shared__ int64_t s_min[kWavesPerBlock], s_max[kWavesPerBlock];
+    __shared__ int64_t s_min[kRWaves], s_max[kRWaves];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (lane == 0) { s_min[wave] = kmin; s_max[wave] = kmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int w = 1; w < kWavesPerBlock; ++w) {
+        for (int w = 1; w < kRWaves; ++w) {
             kmin = s_min[w] < kmin ? s_min[w] : kmin;
             kmax = s_max[w] > kmax ? s_max[w] : kmax;
         }
-        partials[2 * size_t(blockIdx.x)] = kmin;
-        partials[2 * size_t(blockIdx.x) + 1] = kmax;
+        if (keys2_if_single) {
+            keys2_if_single[0] = ~kmin;
+            keys2_if_single[1] = kmax;
+        } else {
+            partials[2 * size_t(blockIdx.x)] = kmin;
+            partials[2 * size_t(blockIdx.x) + 1] = kmax;
+        }
     }
 }
 
@@ -316,7 +331,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 }
 
 template <typename W, int U>
-__global__ __launch_bounds__(kBlock) void k_first_diff_partials(const W* __restrict__ l, const W* __restrict__ r, size_t n,
+__global__ __launch_bounds__(kRBlock) void k_first_diff_partials(const W* __restrict__ l, const W* __restrict__ r, size_t n,
                                                                 uint64_t* __restrict__ partials, bool aligned,
                                                                 unsigned head) {
     constexpr int CPL = 16 / sizeof(W);
@@ -325,13 +340,13 @@ __global__ __launch_bounds__(kBlock) void k_first_diff_partials(const W* __restr
     if (aligned) {
         // `head` leading cells are compared singly by workgroup 0 (see k_min_max_partials); indices stay absolute
         if (blockIdx.x == 0)
-            for (unsigned h = threadIdx.x; h < head; h += kBlock)
+            for (unsigned h = threadIdx.x; h < head; h += kRBlock)
                 if (l[h] != r[h]) first = h < first ? h : first;
         l += head;
         r += head;
         n -= head;
         const size_t ngroups = n / CPL;
-        constexpr size_t TILE = size_t(kBlock) * U;
+        constexpr size_t TILE = size_t(kRBlock) * U;
         const size_t ntiles = (ngroups + TILE - 1) / TILE;
         const WV* __restrict__ lv = reinterpret_cast<const WV*>(l);
         const WV* __restrict__ rv = reinterpret_cast<const WV*>(r);
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_first_diff_partials(const W* __restr
             const size_t base = tile * TILE + threadIdx.x;
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                const size_t g = base + size_t(j) * kBlock;
+                const size_t g = base + size_t(j) * kRBlock;
                 if (g < ngroups) {
                     const WV a = nt_load(lv + g), b = nt_load(rv + g);
 #pragma unroll
@@ -349,20 +364,20 @@ __global__ __launch_bounds__(kBlock) void k_first_diff_partials(const W* __restr
             }
         }
         if (blockIdx.x == 0)
-            for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kBlock)
+            for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kRBlock)
                 if (l[i] != r[i]) first = head + i < first ? head + i : first;
     } else {
-        const size_t stride = size_t(gridDim.x) * kBlock;
-        for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n && first == ~0ull; i += stride)
+        const size_t stride = size_t(gridDim.x) * kRBlock;
+        for (size_t i = size_t(blockIdx.x) * kRBlock + threadIdx.x; i < n && first == ~0ull; i += stride)
             if (l[i] != r[i]) first = i;
     }
     first = wave_min_u64(first);
-    __shared__ uint64_t s_first[kWavesPerBlock];
+    __shared__ uint64_t s_first[kRWaves];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (lane == 0) s_first[wave] = first;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kWavesPerBlock; ++w) first = s_first[w] < first ? s_first[w] : first;
+        for (int w = 1; w < kRWaves; ++w) first = s_first[w] < first ? s_first[w] : first;
         partials[blockIdx.x] = first;
     }
 }
@@ -398,47 +413,62 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 }
 
 template <int U>
-__global__ __launch_bounds__(kBlock) void k_mask_count_partials(const uint8_t* __restrict__ m, size_t n,
-                                                                uint64_t* __restrict__ partials, bool aligned, unsigned head) {
+__global__ __launch_bounds__(kRBlock) void k_mask_count_partials(const uint8_t* __restrict__ m, size_t n,
+                                                                uint64_t* __restrict__ partials, bool aligned, unsigned head,
+                                                                uint64_t* __restrict__ counts2_if_single) {
+    const uint64_t n_total = n;
     uint64_t cnt = 0;
     if (aligned) {
         if (blockIdx.x == 0)  // peeled leading cells (see k_min_max_partials)
-            for (unsigned h = threadIdx.x; h < head; h += kBlock) cnt += m[h] & 1;
+            for (unsigned h = threadIdx.x; h < head; h += kRBlock) cnt += m[h] & 1;
         m += head;
         n -= head;
         const size_t ngroups = n / 16;
-        constexpr size_t TILE = size_t(kBlock) * U;
+        constexpr size_t TILE = size_t(kRBlock) * U;
         const size_t ntiles = (ngroups + TILE - 1) / TILE;
         const u32x4* __restrict__ mv = reinterpret_cast<const u32x4*>(m);
         uint32_t c32 = 0;
         for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const size_t base = tile * TILE + threadIdx.x;
+            auto pop16 = [](u32x4 x) {
+                return __builtin_popcount(x.x & 0x01010101u) + __builtin_popcount(x.y & 0x01010101u) +
+                       __builtin_popcount(x.z & 0x01010101u) + __builtin_popcount(x.w & 0x01010101u);
+            };
+            if (tile * TILE + TILE <= ngroups) {  // full tile: every load in flight before the first popcount
+                u32x4 x[U];
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const size_t g = base + size_t(j) * kBlock;
-                if (g < ngroups) {
-                    u32x4 x = nt_load(mv + g);
-                    c32 += __builtin_popcount(x.x & 0x01010101u) + __builtin_popcount(x.y & 0x01010101u) +
-                           __builtin_popcount(x.z & 0x01010101u) + __builtin_popcount(x.w & 0x01010101u);
+                for (int j = 0; j < U; ++j) x[j] = nt_load(mv + base + size_t(j) * kRBlock);
+#pragma unroll
+                for (int j = 0; j < U; ++j) c32 += pop16(x[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const size_t g = base + size_t(j) * kRBlock;
+                    if (g < ngroups) c32 += pop16(nt_load(mv + g));
                 }
             }
             if (c32 > 0x7fff0000u) { cnt += c32; c32 = 0; }
         }
         cnt += c32;
         if (blockIdx.x == 0)
-            for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) cnt += m[i] & 1;
+            for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kRBlock) cnt += m[i] & 1;
     } else {
-        const size_t stride = size_t(gridDim.x) * kBlock;
-        for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) cnt += m[i] & 1;
+        const size_t stride = size_t(gridDim.x) * kRBlock;
+        for (size_t i = size_t(blockIdx.x) * kRBlock + threadIdx.x; i < n; i += stride) cnt += m[i] & 1;
     }
     cnt = wave_sum_u64(cnt);
-    __shared__ uint64_t s_cnt[kWavesPerBlock];
+    __shared__ uint64_t s_cnt[kRWaves];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (lane == 0) s_cnt[wave] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kWavesPerBlock; ++w) cnt += s_cnt[w];
-        partials[blockIdx.x] = cnt;
+        for (int w = 1; w < kRWaves; ++w) cnt += s_cnt[w];
+        if (counts2_if_single) {  // one-workgroup grid: this IS the result (see k_min_max_partials)
+            counts2_if_single[0] = cnt;
+            counts2_if_single[1] = n_total - cnt;
+        } else {
+            partials[blockIdx.x] = cnt;
+        }
     }
 }
 

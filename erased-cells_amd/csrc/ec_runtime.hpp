@@ -25,7 +25,7 @@ constexpr int kBinopU = 2;         // chunks of 128 cells per wave per tile (U =
 #endif
 constexpr bool kNtStore = EC_NT_STORE;    // streaming f64 output: 2.1 GB ≫ 256 MiB Infinity Cache
 constexpr bool kNtLoad = EC_NT_LOAD;     // +6 % on the divide (tune_binop_v2.log: 6270 -> 6666 GB/s)
-constexpr int kReduceU = 4;
+constexpr int kReduceU = 8;   // 16-byte loads in flight per lane of a reduction tile (ec_reduce_kernels.hpp)
 constexpr int kMaxReduceBlocks = 4096;
 
 struct Tuning;
@@ -34,7 +34,7 @@ Tuning& tuning();
 // launch — a launch sees the old or the new value of each knob, never a torn one; both are valid launch shapes.
 struct Tuning {
     std::atomic<int> binop_variant{0};  // 0 = direct narrow loads, 1 = LDS-staged narrow operands
-    std::atomic<int> reduce_bpc{8};     // blocks per CU for reductions (partials are per block)
+    std::atomic<int> reduce_bpc{4};     // 512-thread workgroups per CU for reductions (partials are per workgroup)
     std::atomic<int> map_u{2};          // 16-B groups per lane per tile for the map kernels (1, 2 or 4)
     std::atomic<int> peel{1};              // leading-cell peel of the binop/fused kernels: 0 off, 1 for 1-byte operands, 2 also for 2-byte ones
     std::atomic<int> unaligned_vector{1};  // 1 = vector kernels at any cell offset (gfx950 unaligned global access);
