@@ -267,10 +267,15 @@ inline ec_stream& current_stream() { static thread_local ec_stream s = nullptr; 
 class DeviceMem {  // one HBM allocation, from the stream-ordered pool (no hipMalloc/hipFree per operator)
     void* p_ = nullptr;
     size_t bytes_ = 0;
+    ec_stream alloc_stream_ = nullptr;
 
 public:
-    explicit DeviceMem(size_t bytes) : bytes_(bytes) { check(ec_alloc_async(&p_, bytes, current_stream())); }
-    ~DeviceMem() { if (p_) ec_free_async(p_, current_stream()); }
+    explicit DeviceMem(size_t bytes) : bytes_(bytes), alloc_stream_(current_stream()) { check(ec_alloc_async(&p_, bytes, alloc_stream_)); }
+    // Back to the pool on the ALLOCATING stream, ordered after everything queued so far on the stream that is current
+    // on the dropping thread (the buffer's last operator ran there if the caller switched streams in between, or if
+    // another thread drops it): freeing on "whatever stream is current" alone would let the pool reuse the block
+    // while kernels on the other stream still touch it.
+    ~DeviceMem() { if (p_) ec_free_ordered(p_, alloc_stream_, current_stream()); }
     DeviceMem(const DeviceMem&) = delete;
     DeviceMem& operator=(const DeviceMem&) = delete;
     void* ptr() const { return p_; }
@@ -809,5 +814,95 @@ template <typename B> inline B eval(const Node<B>& n) { return n.l->binop(n.op, 
 template <typename B> inline B eval(const Tree<B>& t) { return expr(*t.l.l, t.l.op, *t.l.r, t.op, *t.rl, t.rop, t.rr); }
 
 }  // namespace fused
+
+// ---------------------------------------------------------------- one process, all GPUs of the node
+// Row-block shards over an ec_shard_group: shard i on device i, a launch thread + stream + RCCL communicator per
+// device inside the library.  Element-wise ops fan out without communication; min_max / counts all-reduce their
+// 16-byte payloads over xGMI.  (One process per GPU instead: ec_comm_init_rank + ec_allreduce_*.)
+namespace sharded {
+
+class ShardGroup {
+    ec_shard_group* g_ = nullptr;
+    int n_ = 0;
+
+public:
+    explicit ShardGroup(const std::vector<int32_t>& devices, uint32_t flags = EC_GROUP_RCCL) : n_(static_cast<int>(devices.size())) {
+        check(ec_shard_group_create(devices.data(), n_, flags, &g_));
+    }
+    ~ShardGroup() { ec_shard_group_destroy(g_); }
+    ShardGroup(const ShardGroup&) = delete;
+    ShardGroup& operator=(const ShardGroup&) = delete;
+    ec_shard_group* raw() const { return g_; }
+    int size() const { return n_; }
+    void sync() const { check(ec_shard_group_sync(g_)); }
+};
+
+class ShardedCellBuffer {
+    const ShardGroup* grp_;
+    CellType ct_;
+    std::vector<void*> ptrs_;
+    std::vector<size_t> lens_;
+
+    ShardedCellBuffer(const ShardGroup& g, CellType ct, std::vector<size_t> lens) : grp_(&g), ct_(ct), ptrs_(lens.size(), nullptr), lens_(std::move(lens)) {
+        std::vector<size_t> bytes;
+        for (size_t l : lens_) bytes.push_back(l * size_of(ct));
+        check(ec_sharded_alloc(grp_->raw(), bytes.data(), ptrs_.data()));
+    }
+
+public:
+    ShardedCellBuffer(ShardedCellBuffer&& o) noexcept : grp_(o.grp_), ct_(o.ct_), ptrs_(std::move(o.ptrs_)), lens_(std::move(o.lens_)) { o.ptrs_.clear(); }
+    ShardedCellBuffer(const ShardedCellBuffer&) = delete;
+    ~ShardedCellBuffer() {
+        if (!ptrs_.empty()) { ec_shard_group_sync(grp_->raw()); ec_sharded_free(grp_->raw(), ptrs_.data()); }
+    }
+    // `From<Vec<T>>` of a row-major n_rows x n_cols raster: contiguous row-blocks, block i to device i
+    template <typename T> static ShardedCellBuffer scatter(const ShardGroup& g, const std::vector<T>& data, uint64_t n_rows, uint64_t n_cols) {
+        std::vector<size_t> lens, offs, bytes;
+        for (int i = 0; i < g.size(); ++i) {
+            uint64_t o = 0, l = 0;
+            check(ec_shard_range(n_rows, n_cols, static_cast<uint32_t>(i), static_cast<uint32_t>(g.size()), &o, &l));
+            lens.push_back(l); offs.push_back(o * sizeof(T)); bytes.push_back(l * sizeof(T));
+        }
+        ShardedCellBuffer b(g, CellEncoding<T>::cell_type(), lens);
+        check(ec_sharded_upload(g.raw(), b.ptrs_.data(), data.data(), offs.data(), bytes.data()));
+        return b;
+    }
+    CellType cell_type() const { return ct_; }
+    size_t len() const { size_t n = 0; for (size_t l : lens_) n += l; return n; }
+    const std::vector<size_t>& shard_lens() const { return lens_; }
+    // impl {Add,Sub,Mul,Div} for &CellBuffer on every shard (buffer.rs:324-329); operands sharded identically
+    ShardedCellBuffer binop(ec_op op, const ShardedCellBuffer& rhs) const {
+        if (lens_ != rhs.lens_) throw Error(EC_ERR_LENGTH, "operands must be sharded identically");
+        ShardedCellBuffer out(*grp_, CellType::Float64, lens_);
+        std::vector<const void*> l(ptrs_.begin(), ptrs_.end()), r(rhs.ptrs_.begin(), rhs.ptrs_.end());
+        std::vector<double*> o;
+        for (void* p : out.ptrs_) o.push_back(static_cast<double*>(p));
+        check(ec_sharded_binop(grp_->raw(), op, static_cast<ec_dtype>(ct_), l.data(), static_cast<ec_dtype>(rhs.ct_), r.data(), lens_.data(), o.data()));
+        return out;
+    }
+    ShardedCellBuffer operator+(const ShardedCellBuffer& r) const { return binop(EC_ADD, r); }
+    ShardedCellBuffer operator-(const ShardedCellBuffer& r) const { return binop(EC_SUB, r); }
+    ShardedCellBuffer operator*(const ShardedCellBuffer& r) const { return binop(EC_MUL, r); }
+    ShardedCellBuffer operator/(const ShardedCellBuffer& r) const { return binop(EC_DIV, r); }
+    // BufferOps::min_max of the whole raster (buffer.rs:169-173): per-shard keys, one all-reduce(MAX), decode
+    std::pair<CellValue, CellValue> min_max() const {
+        ec_value mn, mx;
+        std::vector<const void*> p(ptrs_.begin(), ptrs_.end());
+        check(ec_sharded_min_max(grp_->raw(), static_cast<ec_dtype>(ct_), p.data(), nullptr, lens_.data(), &mn, &mx));
+        return {CellValue(mn), CellValue(mx)};
+    }
+    template <typename T> std::vector<T> to_vec() const {  // gather; T must be the buffer's own cell type
+        if (CellEncoding<T>::cell_type() != ct_) throw NarrowingError(ct_, CellEncoding<T>::cell_type());
+        std::vector<T> out(len());
+        std::vector<size_t> offs, bytes;
+        size_t acc = 0;
+        for (size_t l : lens_) { offs.push_back(acc * sizeof(T)); bytes.push_back(l * sizeof(T)); acc += l; }
+        std::vector<const void*> p(ptrs_.begin(), ptrs_.end());
+        check(ec_sharded_download(grp_->raw(), out.data(), p.data(), offs.data(), bytes.data()));
+        return out;
+    }
+};
+
+}  // namespace sharded
 
 }  // namespace erased_cells

@@ -449,6 +449,34 @@ static void debug_format_checks() {
     CHECK(rust_debug<int8_t>(-5) == "-5" && rust_debug<uint8_t>(200) == "200" && rust_debug<uint64_t>(18446744073709551615ull) == "18446744073709551615");
 }
 
+// One process driving "several" GPUs: a 1-GPU box lists device 0 three times under EC_GROUP_HOST_COMBINE (launch
+// threads, row-block scatter/gather, fan-out and the combine all run; only the xGMI hop does not), and once over RCCL.
+static void sharded_tests() {
+    using namespace sharded;
+    const uint64_t rows = 37, cols = 53;
+    std::vector<uint16_t> x(rows * cols), d(rows * cols);
+    for (size_t i = 0; i < x.size(); ++i) { x[i] = static_cast<uint16_t>(1000 + (i * 7919u) % 50000u); d[i] = static_cast<uint16_t>(1 + (i * 104729u) % 65535u); }
+    x[5] = 3; x[x.size() - 9] = 65000;  // extremes in the first and the last shard
+    CellBuffer whole_x = CellBuffer::from_vec(x), whole_d = CellBuffer::from_vec(d);
+    const auto want_q = (whole_x / whole_d).to_vec<double>();
+    const auto want_mm = whole_x.min_max();
+    for (int variant = 0; variant < 2; ++variant) {
+        ShardGroup g(variant == 0 ? std::vector<int32_t>{0, 0, 0} : std::vector<int32_t>{0},
+                     variant == 0 ? EC_GROUP_HOST_COMBINE : EC_GROUP_RCCL);
+        auto sx = ShardedCellBuffer::scatter(g, x, rows, cols), sd = ShardedCellBuffer::scatter(g, d, rows, cols);
+        CHECK(sx.len() == x.size() && sx.cell_type() == CellType::UInt16);
+        if (variant == 0) CHECK((sx.shard_lens() == std::vector<size_t>{13 * cols, 12 * cols, 12 * cols}));
+        auto q = sx / sd;
+        CHECK(q.cell_type() == CellType::Float64);
+        const auto got = q.to_vec<double>();
+        CHECK(got.size() == want_q.size() && std::memcmp(got.data(), want_q.data(), got.size() * sizeof(double)) == 0);
+        const auto mm = sx.min_max();
+        CHECK(mm.first == want_mm.first && mm.second == want_mm.second);
+        CHECK(mm.first == CellValue(uint16_t(3)) && mm.second == CellValue(uint16_t(65000)));
+        CHECK(sx.to_vec<uint16_t>() == x);
+    }
+}
+
 int main(int argc, char** argv) {
     bool host_only = argc > 1 && std::string(argv[1]) == "--host-only";
     const char* dd = std::getenv("TEST_DATA_DIR");  // as the reference's testkit (.cargo/config.toml:3)
@@ -463,6 +491,7 @@ int main(int argc, char** argv) {
             buffer_tests();
             mask_tests();
             masked_tests();
+            sharded_tests();
             if (dd) gdal_tests(dd);
         } else {
             nodata_tests();

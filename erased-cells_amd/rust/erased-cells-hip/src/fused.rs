@@ -2,9 +2,14 @@
 //!
 //! The reference evaluates `(&nir - &red) / (nir + red)` (src/gdal/rasterband.rs:148,178) eagerly, one f64
 //! temporary per operator.  Every step of such a chain is already an f64 rounded once (src/value.rs:207), so
-//! `ec_fused` produces the same bits from a single kernel.  Operands are buffers or scalars.
+//! `ec_fused` produces the same bits from a single kernel.  Operands are buffers or scalars; buffers of one cell
+//! type, or of two (e.g. a UInt16 and a Float32 band), run as one pass without temporaries.
+use crate::device::stream;
+use crate::error::must;
 use crate::ffi::*;
-use crate::{must, stream, CellBuffer, CellType, CellValue, Mask, MaskedCellBuffer};
+use crate::{BufferOps, CellBuffer, CellType, CellValue};
+#[cfg(feature = "masked")]
+use crate::{Mask, MaskedCellBuffer};
 use std::os::raw::c_void;
 
 /// One operand of a fused chain.
@@ -14,14 +19,20 @@ pub enum Operand<'a> {
 }
 
 impl<'a> From<&'a CellBuffer> for Operand<'a> {
-    fn from(b: &'a CellBuffer) -> Self { Operand::Buffer(b) }
+    fn from(b: &'a CellBuffer) -> Self {
+        Operand::Buffer(b)
+    }
 }
 impl<'a> From<CellValue> for Operand<'a> {
-    fn from(v: CellValue) -> Self { Operand::Scalar(v) }
+    fn from(v: CellValue) -> Self {
+        Operand::Scalar(v)
+    }
 }
 impl<'a> Operand<'a> {
     /// `Operand::scalar(2.0)`, `Operand::scalar(3u8)` — any primitive a cell can hold.
-    pub fn scalar<T: Into<CellValue>>(v: T) -> Self { Operand::Scalar(v.into()) }
+    pub fn scalar<T: Into<CellValue>>(v: T) -> Self {
+        Operand::Scalar(v.into())
+    }
 }
 
 /// `(x o1 y) o2 z` when `tail` is `None`, `(x o1 y) o2 (z o3 w)` when it is `Some((o3, w))`.
@@ -63,6 +74,7 @@ pub fn ndvi(nir: &CellBuffer, red: &CellBuffer) -> CellBuffer {
 
 /// The masked form of [`ndvi`]: values as above over all cells, mask = AND of the operand masks
 /// (src/masked/masked_buffer.rs:326-335 applied per step).
+#[cfg(feature = "masked")]
 pub fn ndvi_masked(nir: &MaskedCellBuffer, red: &MaskedCellBuffer) -> MaskedCellBuffer {
     let n = nir.len().min(red.len());
     if n == 0 {
@@ -72,9 +84,12 @@ pub fn ndvi_masked(nir: &MaskedCellBuffer, red: &MaskedCellBuffer) -> MaskedCell
     let p = [nir.buffer().dev_ptr(), red.buffer().dev_ptr(), nir.buffer().dev_ptr(), red.buffer().dev_ptr()];
     let m = [nir.mask().dev_ptr(), red.mask().dev_ptr(), nir.mask().dev_ptr(), red.mask().dev_ptr()];
     let (out, om) = (CellBuffer::uninit(CellType::Float64, n), Mask::uninit(n));
-    must(unsafe {
-        ec_masked_fused(EC_SUB, EC_DIV, EC_ADD, dt.as_ptr(), p.as_ptr(), m.as_ptr(), std::ptr::null(), n,
-                        out.mem.ptr() as *mut f64, om.dev_ptr_mut(), stream())
-    }, "ec_masked_fused");
+    must(
+        unsafe {
+            ec_masked_fused(EC_SUB, EC_DIV, EC_ADD, dt.as_ptr(), p.as_ptr(), m.as_ptr(), std::ptr::null(), n,
+                            out.mem.ptr() as *mut f64, om.dev_ptr_mut(), stream())
+        },
+        "ec_masked_fused",
+    );
     MaskedCellBuffer::new(out, om)
 }

@@ -1,128 +1,149 @@
-//! Device-resident `CellBuffer` / `Mask` / `MaskedCellBuffer` whose operator bodies are calls into
-//! liberased_cells_hip.so (C ABI: include/erased_cells.h).
+//! `erased_cells` with the per-cell arithmetic on an MI355X: device-resident `CellBuffer` / `Mask` /
+//! `MaskedCellBuffer` whose operator bodies are calls into liberased_cells_hip.so (C ABI: include/erased_cells.h).
 //!
-//! The shape follows erased-cells 0.1.1: `CellType` keeps its discriminants (they ARE the ABI dtype
-//! codes), the host keeps the type tag, zip truncation, the empty-result-is-UInt8 rule and the length
-//! asserts, and each per-cell loop body of the reference becomes one FFI call on HBM-resident cells.
+//! The public surface is the reference's (erased-cells 0.1.1): the same three core enums-by-name [`CellType`],
+//! [`CellValue`], [`CellBuffer`], the [`BufferOps`] and [`CellEncoding`] traits, the `with_ct!` macro, and — with
+//! the `masked` feature — [`Mask`], [`MaskedCellBuffer`], [`NoData`], `IsNodata`.  `CellType` keeps its
+//! discriminants (they ARE the ABI dtype codes); the host keeps the type tag, zip truncation, the
+//! empty-result-is-UInt8 rule and the length asserts; each per-cell loop body of the reference becomes one FFI
+//! call on HBM-resident cells.  What differs: `CellBuffer` is a struct (tag + length + device block) instead of
+//! an enum over `Vec<T>`, so code that matches on `CellBuffer::UInt8(vec)` must call `to_vec::<u8>()` instead;
+//! `Error` has one more variant (`Backend`).  Extras: [`fused`] (operator chains in one pass), [`sharded`]
+//! (row-block shards over the GPUs of a node), [`init`] / [`set_stream`].
 //!
-//! NOT COMPILED in the build image (no rustc there); `tests/test_abi_host.py` keeps `ffi.rs` in lockstep
-//! with the header.  The same mapping, compiled and tested, exists in C++ (`host/erased_cells.hpp`) and
-//! Python (`python/erased_cells_hip/buffer.py`); see INTEGRATION.md.
+//! NOT COMPILED in the build image (no rustc there); `tests/test_rust_surface.py` keeps the public items in
+//! lockstep with the reference's and `ffi.rs` in lockstep with the header.  The same mapping, compiled and
+//! tested, exists in C++ (`host/erased_cells.hpp`) and Python (`python/erased_cells_hip`); see INTEGRATION.md.
 pub mod ffi;
 
+mod cell_encoding;
+mod cell_type;
 mod cell_value;
+mod device;
 mod device_buffer;
+#[cfg(feature = "masked")]
 mod device_mask;
+#[path = "errors.rs"]
+pub mod error;
 pub mod fused;
+#[cfg(feature = "masked")]
 mod masked;
+#[cfg(feature = "masked")]
+mod nodata;
 pub mod sharded;
 
-pub use cell_value::CellValue;
-pub use device_buffer::CellBuffer;
-pub use device_mask::Mask;
-pub use masked::{MaskedCellBuffer, NoData};
+pub use cell_encoding::*;
+pub use cell_type::*;
+pub use cell_value::*;
+pub use device::{init, set_stream, stream};
+pub use device_buffer::*;
+#[cfg(feature = "masked")]
+pub use device_mask::*;
+#[cfg(feature = "masked")]
+pub use masked::*;
+#[cfg(feature = "masked")]
+pub use nodata::*;
+use std::fmt::{Debug, Formatter};
 
-use ffi::*;
-use std::ffi::CStr;
-use std::os::raw::c_void;
-use std::ptr;
-
-/// `CellType` (src/ctype.rs:11-20, variant order of src/lib.rs:89-98): `self as u8` is the ABI dtype code.
-#[derive(Debug, Copy, Clone, PartialEq, Eq, PartialOrd, Ord, Hash)]
-#[repr(u8)]
-pub enum CellType { UInt8, UInt16, UInt32, UInt64, Int8, Int16, Int32, Int64, Float32, Float64 }
-
-impl CellType {
-    pub(crate) fn from_code(c: u8) -> Self {
-        assert!(c <= CellType::Float64 as u8, "dtype code {c} out of range");
-        unsafe { std::mem::transmute(c) }
-    }
-    pub fn size_of(self) -> usize { unsafe { ec_size_of(self as u8) } }
-    /// src/ctype.rs:99-121
-    pub fn union(self, other: Self) -> Self { Self::from_code(unsafe { ec_union(self as u8, other as u8) }) }
-    /// src/ctype.rs:124-131
-    pub fn can_fit_into(self, other: Self) -> bool { unsafe { ec_can_fit_into(self as u8, other as u8) != 0 } }
-    /// src/ctype.rs:158-167
-    pub fn min_value(self) -> CellValue {
-        let mut v = CellValue::UInt8(0).to_ffi();
-        unsafe { ec_min_value(self as u8, &mut v) };
-        CellValue::from_ffi(&v)
-    }
-    /// src/ctype.rs:170-179
-    pub fn max_value(self) -> CellValue {
-        let mut v = CellValue::UInt8(0).to_ffi();
-        unsafe { ec_max_value(self as u8, &mut v) };
-        CellValue::from_ffi(&v)
-    }
-}
-
-/// Implemented by the ten primitives a cell can hold (src/encoding.rs).
-pub trait CellEncoding: Copy + Into<CellValue> {
-    fn cell_type() -> CellType;
-}
-macro_rules! encoding {
-    ($(($id:ident, $p:ident)),*) => { $(
-        impl CellEncoding for $p { fn cell_type() -> CellType { CellType::$id } }
-    )* }
-}
-encoding!((UInt8, u8), (UInt16, u16), (UInt32, u32), (UInt64, u64), (Int8, i8), (Int16, i16), (Int32, i32),
-          (Int64, i64), (Float32, f32), (Float64, f64));
-
-#[derive(thiserror::Error, Debug)]
-pub enum Error {
-    /// src/error.rs: narrowing conversions are refused (ctype lattice), never performed lossily
-    #[error("Invalid narrowing from cell-type {src:?} to {dst:?}")]
-    NarrowingError { src: CellType, dst: CellType },
-    #[error("HIP backend: {0}")]
-    Backend(String),
-}
-pub type Result<T> = std::result::Result<T, Error>;
-
-pub(crate) fn check(st: ec_status) -> Result<()> {
-    if st == EC_OK {
-        return Ok(());
-    }
-    if st == EC_ERR_NARROWING {
-        let (mut s, mut d) = (0u8, 0u8);
-        unsafe { ec_last_narrowing(&mut s, &mut d) };
-        return Err(Error::NarrowingError { src: CellType::from_code(s), dst: CellType::from_code(d) });
-    }
-    Err(Error::Backend(unsafe { CStr::from_ptr(ec_last_error_string()) }.to_string_lossy().into_owned()))
-}
-
-/// Arithmetic is infallible in the reference; a backend failure (no device, out of HBM) is a panic.
-pub(crate) fn must(st: ec_status, what: &str) {
-    if let Err(e) = check(st) {
-        panic!("{what}: {e}");
-    }
-}
-
-/// Bind the process to one GPU (one process per GPU; call once before any buffer exists).
-pub fn init(device: i32) -> Result<()> { check(unsafe { ec_init(device) }) }
-
-/// The stream every call of this crate is issued on (the default stream; a host that owns streams
-/// passes its own `hipStream_t` through the same parameter).
-pub(crate) fn stream() -> ec_stream { ptr::null_mut() }
-
-/// One HBM allocation from the stream-ordered pool: operator results are allocated per call, as the
-/// reference `collect()`s a fresh `Vec`, and hipMalloc/hipFree per operator would cost as much as the kernel.
-pub(crate) struct DeviceMem {
-    ptr: *mut c_void,
-}
-impl DeviceMem {
-    pub(crate) fn new(bytes: usize) -> Self {
-        let mut p = ptr::null_mut();
-        if bytes > 0 {
-            must(unsafe { ec_alloc_async(&mut p, bytes, stream()) }, "ec_alloc_async");
+/// `with_ct` is a callback style macro used to construct various implementations covering all [`CellType`]s.
+///
+/// It calls the passed identifier as a macro with two parameters: the cell type id (e.g. `UInt8`) and the cell
+/// type primitive (e.g. `u8`), for each of the ten encodings, in discriminant order.
+#[macro_export]
+macro_rules! with_ct {
+    ($callback:ident) => {
+        $callback! {
+            (UInt8, u8),
+            (UInt16, u16),
+            (UInt32, u32),
+            (UInt64, u64),
+            (Int8, i8),
+            (Int16, i16),
+            (Int32, i32),
+            (Int64, i64),
+            (Float32, f32),
+            (Float64, f64)
         }
-        Self { ptr: p }
-    }
-    pub(crate) fn ptr(&self) -> *mut c_void { self.ptr }
+    };
 }
-impl Drop for DeviceMem {
-    fn drop(&mut self) {
-        if !self.ptr.is_null() {
-            unsafe { ec_free_async(self.ptr, stream()) };
+
+/// Operations common to buffers of [`CellValue`]s.
+pub trait BufferOps {
+    /// Construct a [`CellBuffer`] from a `Vec<T>`.
+    fn from_vec<T: CellEncoding>(data: Vec<T>) -> Self;
+
+    /// Construct a [`CellBuffer`] of given `len` length and `ct` `CellType`, filled with the type's default value.
+    fn with_defaults(len: usize, ct: CellType) -> Self;
+
+    /// Create a buffer of size `len` with all values `value`.
+    fn fill(len: usize, value: CellValue) -> Self;
+
+    /// Fill a buffer of size `len` with values from a closure called with the current index.
+    fn fill_via<T, F>(len: usize, f: F) -> Self
+    where
+        T: CellEncoding,
+        F: Fn(usize) -> T;
+
+    /// Get the length of the buffer.
+    fn len(&self) -> usize;
+
+    /// Determine if the buffer has zero values in it.
+    fn is_empty(&self) -> bool {
+        self.len() == 0
+    }
+
+    /// Get the cell-type of the encoded value.
+    fn cell_type(&self) -> CellType;
+
+    /// Get the [`CellValue`] at index `idx`.
+    ///
+    /// # Panics
+    /// Will panic if `index` >= `self.len()`.
+    fn get(&self, index: usize) -> CellValue;
+
+    /// Store `value` at position `idx`.
+    ///
+    /// Returns `Err(NarrowingError)` if `value.cell_type() != self.cell_type()` and overflow could occur.
+    ///
+    /// # Panics
+    /// Will panic if `index` >= `self.len()`.
+    fn put(&mut self, index: usize, value: CellValue) -> error::Result<()>;
+
+    /// Create a new buffer whereby all [`CellValue`]s are converted to `cell_type`.
+    ///
+    /// Returns `Err(NarrowingError)` if `cell_type` is narrower than the buffer's cell type.
+    fn convert(&self, cell_type: CellType) -> error::Result<Self>
+    where
+        Self: Sized;
+
+    /// Compute the minimum and maximum values the buffer.
+    fn min_max(&self) -> (CellValue, CellValue);
+
+    /// Convert `self` into a `Vec<T>`.
+    fn to_vec<T: CellEncoding>(self) -> error::Result<Vec<T>>;
+}
+
+/// Newtype wrapper for debug rendering: more than ten items show as the first five, `, ... `, the last five.
+pub(crate) struct Elided<'a, T>(&'a [T]);
+
+impl<T: Debug> Debug for Elided<'_, T> {
+    fn fmt(&self, f: &mut Formatter<'_>) -> std::fmt::Result {
+        let v = self.0;
+        let show = |f: &mut Formatter<'_>, part: &[T]| -> std::fmt::Result {
+            for (i, x) in part.iter().enumerate() {
+                if i > 0 {
+                    f.write_str(", ")?;
+                }
+                f.write_fmt(format_args!("{x:?}"))?;
+            }
+            Ok(())
+        };
+        if v.len() > 10 {
+            show(f, &v[..5])?;
+            f.write_str(", ... ")?;
+            show(f, &v[v.len() - 5..])
+        } else {
+            show(f, v)
         }
     }
 }
