@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--side", type=int, default=16384, help="raster is side x side cells")
+    ap.add_argument("--rows", type=int, default=None,
+                    help="raster rows (default: side); e.g. --rows 2048 times on one GPU the row-block one rank owns at N=8")
     ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax", "ndvi"])
     ap.add_argument("--fused", action="store_true", help="masked_chain / ndvi: the single-pass fused kernel instead of the eager chain")
     ap.add_argument("--mixed", action="store_true", help="ndvi: red band as f32 (mixed operand types -> the generic fused kernel)")
@@ -282,7 +284,7 @@ def main():
     ec.set_stream(stream)
 
     side = args.side
-    rows_total = side * (world if args.scaling == "weak" else 1)
+    rows_total = (args.rows or side) * (world if args.scaling == "weak" else 1)
     off, n = sharded.shard_range(rows_total, side, rank, world)
     total_cells = rows_total * side
 
@@ -300,7 +302,7 @@ def main():
         chk(L.ec_synth_fill(ec.UInt8, a.mem.ptr, n, 0x5EED0001, off, 0.0, 255.0, stream))
         chk(L.ec_synth_fill(ec.UInt16, b.mem.ptr, n, 0x5EED0002, off, 1.0, 65535.0, stream))
         bytes_per_cell, kernel = 11, "k_binop_direct<u8,u16,Div>" if (args.variant or 0) == 0 else "k_binop_lds<u8,u16,Div>"
-        wl = f"{side}x{side} u8/u16->f64 CellBuffer divide (BASELINE configs[1])"
+        wl = f"{args.rows or side}x{side} u8/u16->f64 CellBuffer divide (BASELINE configs[1]" + (")" if not args.rows else f"; the row-block of 1/{max(1, side // args.rows)} shard)")
 
         def step():
             chk(L.ec_binop(ec.DIV, ec.UInt8, a.mem.ptr, ec.UInt16, b.mem.ptr, n, out.mem.ptr, stream))
@@ -395,6 +397,9 @@ def main():
         ec.set_stream(stream)
         graph.replay()  # first replay uploads the graph
         torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.disable()  # a collector pause inside a 1 ms timed region (K steps of a 1/8 shard) would be a tenth of it
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -407,6 +412,7 @@ def main():
     ev1.record()
     torch.cuda.synchronize()              # this rank's K steps are complete on the device
     elapsed = time.perf_counter() - t0    # per-rank time of exactly K steps; the MAX over ranks is reported
+    gc.enable()
     barrier()                             # closing bracket: every rank is done before anything else happens
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream
 

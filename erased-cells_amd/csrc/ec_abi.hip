@@ -25,6 +25,14 @@ static_assert(kMaxReduceBlocks <= kFinalizeMaxParts, "the finalize kernels read 
 
 static ec_status ensure_init() { return ensure_ready(); }
 
+// Workgroups a reduction launches at most: `per_cu` per CU (the launch shape's own default: as many as are resident
+// at once, so the grid runs as one round) unless "reduce_bpc" overrides it; never more than the finalize kernels read.
+static int reduce_cap(int per_cu) {
+    const int knob = tuning().reduce_bpc;
+    const long cap = long(device_cus()) * (knob > 0 ? knob : per_cu);
+    return static_cast<int>(cap < kMaxReduceBlocks ? cap : kMaxReduceBlocks);
+}
+
 static inline hipStream_t S(ec_stream s) { return static_cast<hipStream_t>(s); }
 
 template <typename Fn, int U>
@@ -93,17 +101,31 @@ static ec_status launch_min_max(const void* p, const uint8_t* mask, size_t n, in
     unsigned grid = 0;
     if (n > 0) {
         const bool al = aligned16(p, p, p) && (!mask || aligned_to(mask, 16 / sizeof(T)));
-        int cap = device_cus() * tuning().reduce_bpc;
-        if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
+        const int cap = reduce_cap(8);  // the cell-wise kernel: 256-thread workgroups
         if (al) {
             const unsigned head = reduce_head(p, sizeof(T), n);
             const size_t groups = (n - head) / (16 / sizeof(T));
-            size_t tiles = (groups + size_t(kRBlock) * kReduceU - 1) / (size_t(kRBlock) * kReduceU);
-            if (tiles < 1) tiles = 1;
-            grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
-            int64_t* direct = grid == 1 ? keys2_dev : nullptr;  // one workgroup: it writes the result itself
-            if (mask) k_min_max_partials<T, true, kReduceU><<<grid, kRBlock, 0, s>>>(tp, mask, n, sc.dev, head, direct);
-            else k_min_max_partials<T, false, kReduceU><<<grid, kRBlock, 0, s>>>(tp, nullptr, n, sc.dev, head, direct);
+            // launch shape: 512 threads x 8 loads in flight by default; "reduce_shape" selects the A/B alternatives
+            auto launch = [&](auto u_tag, auto block_tag, int per_cu) {
+                constexpr int U = decltype(u_tag)::value, BLOCK = decltype(block_tag)::value;
+                const int cap2 = reduce_cap(per_cu);
+                size_t tiles = (groups + size_t(BLOCK) * U - 1) / (size_t(BLOCK) * U);
+                if (tiles < 1) tiles = 1;
+                grid = static_cast<unsigned>(tiles < size_t(cap2) ? tiles : size_t(cap2));
+                int64_t* direct = grid == 1 ? keys2_dev : nullptr;  // one workgroup: it writes the result itself
+                if (mask) k_min_max_partials<T, true, U, BLOCK><<<grid, BLOCK, 0, s>>>(tp, mask, n, sc.dev, head, direct);
+                else k_min_max_partials<T, false, U, BLOCK><<<grid, BLOCK, 0, s>>>(tp, nullptr, n, sc.dev, head, direct);
+                return direct != nullptr;
+            };
+            using std::integral_constant;
+            bool direct = false;
+            switch (tuning().reduce_shape) {
+                case 1: direct = launch(integral_constant<int, 16>{}, integral_constant<int, 512>{}, 4); break;
+                case 2: direct = launch(integral_constant<int, 8>{}, integral_constant<int, 256>{}, 8); break;
+                case 3: direct = launch(integral_constant<int, 8>{}, integral_constant<int, 1024>{}, 2); break;
+                case 4: direct = launch(integral_constant<int, 4>{}, integral_constant<int, 512>{}, 4); break;
+                default: direct = launch(integral_constant<int, kReduceU>{}, integral_constant<int, kRBlock>{}, 4); break;
+            }
             if (direct) return check_launch("min_max(single workgroup)");
         } else {
             size_t blocks = (n + kBlock - 1) / kBlock;
@@ -366,8 +388,7 @@ extern "C" ec_status ec_min_max(ec_dtype t, const void* p, const uint8_t* mask_o
 // =================================================================== Ord / Eq
 template <typename W>
 static ec_status first_diff_w(const void* l, const void* r, size_t n, const Scratch& sc, hipStream_t s, unsigned* grid_out) {
-    int cap = device_cus() * tuning().reduce_bpc;
-    if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
+    const int cap = reduce_cap(4);
     const bool al = aligned16(l, r, r);
     const unsigned head = al ? reduce_head(l, sizeof(W), n) : 0u;
     size_t tiles = al ? ((n - head) / (16 / sizeof(W)) + size_t(kRBlock) * kReduceU - 1) / (size_t(kRBlock) * kReduceU) : (n + kRBlock - 1) / kRBlock;
@@ -523,8 +544,7 @@ extern "C" ec_status ec_mask_counts_device(const uint8_t* m, size_t n, uint64_t*
     if (st != EC_OK) return st;
     unsigned grid = 0;
     if (n > 0) {
-        int cap = device_cus() * tuning().reduce_bpc;
-        if (cap > kMaxReduceBlocks) cap = kMaxReduceBlocks;
+        const int cap = reduce_cap(4);
         const bool al = aligned_to(m, 16);
         const unsigned head = al ? reduce_head(m, 1, n) : 0u;
         size_t tiles = al ? ((n - head) / 16 + size_t(kRBlock) * kReduceU - 1) / (size_t(kRBlock) * kReduceU) : (n + kRBlock - 1) / kRBlock;

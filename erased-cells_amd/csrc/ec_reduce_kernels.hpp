@@ -135,8 +135,8 @@ constexpr int kRBlock = 512;
 constexpr int kRWaves = kRBlock / kWave;
 
 // partials[2*b] = min key, partials[2*b+1] = max key of block b (int64 order keys).
-template <typename T, bool MASKED, int U>
-__global__ __launch_bounds__(kRBlock) void k_min_max_partials(const T* __restrict__ p, const uint8_t* __restrict__ mask,
+template <typename T, bool MASKED, int U, int BLOCK = kRBlock>
+__global__ __launch_bounds__(BLOCK) void k_min_max_partials(const T* __restrict__ p, const uint8_t* __restrict__ mask,
                                                              size_t n, int64_t* __restrict__ partials, unsigned head,
                                                              int64_t* __restrict__ keys2_if_single) {
     // keys2_if_single != nullptr (only with a one-workgroup grid): this workgroup's fold IS the result, so it writes
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kRBlock) void k_min_max_partials(const T* __restric
     bf.init();
 
     const size_t ngroups = n / CPL;
-    constexpr size_t TILE = size_t(kRBlock) * U;
+    constexpr size_t TILE = size_t(BLOCK) * U;
     const size_t ntiles = (ngroups + TILE - 1) / TILE;
     const TV* __restrict__ pv = reinterpret_cast<const TV*>(p);
     const MV* __restrict__ mv = reinterpret_cast<const MV*>(mask);
@@ -192,15 +192,15 @@ __global__ __launch_bounds__(kRBlock) void k_min_max_partials(const T* __restric
             MV m[U] = {};
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                x[j] = nt_load(pv + base + size_t(j) * kRBlock);
-                if constexpr (MASKED) m[j] = nt_load(mv + base + size_t(j) * kRBlock);
+                x[j] = nt_load(pv + base + size_t(j) * BLOCK);
+                if constexpr (MASKED) m[j] = nt_load(mv + base + size_t(j) * BLOCK);
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) fold(x[j], m[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                const size_t g = base + size_t(j) * kRBlock;
+                const size_t g = base + size_t(j) * BLOCK;
                 if (g < ngroups) {
                     MV m = {};
                     if constexpr (MASKED) m = plain_load(mv + g);
@@ -228,18 +228,18 @@ __global__ __launch_bounds__(kRBlock) void k_min_max_partials(const T* __restric
             amin = key < amin ? key : amin;
             amax = key > amax ? key : amax;
         };
-        for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kRBlock) fold_cell(static_cast<ptrdiff_t>(i));
-        for (unsigned h = threadIdx.x; h < head; h += kRBlock) fold_cell(-static_cast<ptrdiff_t>(h) - 1);  // the peeled cells
+        for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += BLOCK) fold_cell(static_cast<ptrdiff_t>(i));
+        for (unsigned h = threadIdx.x; h < head; h += BLOCK) fold_cell(-static_cast<ptrdiff_t>(h) - 1);  // the peeled cells
     }
     int64_t kmin = wave_min_i64(acc_to_i64<A>(amin));
     int64_t kmax = wave_max_i64(acc_to_i64<A>(amax));
-    __shared__ int64_t s_min[kRWaves], s_max[kRWaves];
+    __shared__ int64_t s_min[(BLOCK / kWave)], s_max[(BLOCK / kWave)];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     if (lane == 0) { s_min[wave] = kmin; s_max[wave] = kmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int w = 1; w < kRWaves; ++w) {
+        for (int w = 1; w < (BLOCK / kWave); ++w) {
             kmin = s_min[w] < kmin ? s_min[w] : kmin;
             kmax = s_max[w] > kmax ? s_max[w] : kmax;
         }

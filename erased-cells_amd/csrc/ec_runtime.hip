@@ -415,7 +415,8 @@ extern "C" ec_status ec_stat_get(const char* key, int64_t* value) {
 extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     if (!key) return set_error(EC_ERR_ARG, "ec_tune_set: null key");
     if (!std::strcmp(key, "binop_variant")) g_tuning.binop_variant = static_cast<int>(value);
-    else if (!std::strcmp(key, "reduce_bpc")) g_tuning.reduce_bpc = value > 0 ? static_cast<int>(value) : 4;
+    else if (!std::strcmp(key, "reduce_bpc")) g_tuning.reduce_bpc = value > 0 ? static_cast<int>(value) : 0;
+    else if (!std::strcmp(key, "reduce_shape")) g_tuning.reduce_shape = static_cast<int>(value);
     else if (!std::strcmp(key, "map_u")) g_tuning.map_u = static_cast<int>(value);
     else if (!std::strcmp(key, "peel")) g_tuning.peel = static_cast<int>(value);
     else if (!std::strcmp(key, "unaligned_vector")) g_tuning.unaligned_vector = value != 0;

@@ -34,7 +34,8 @@ Tuning& tuning();
 // launch — a launch sees the old or the new value of each knob, never a torn one; both are valid launch shapes.
 struct Tuning {
     std::atomic<int> binop_variant{0};  // 0 = direct narrow loads, 1 = LDS-staged narrow operands
-    std::atomic<int> reduce_bpc{4};     // 512-thread workgroups per CU for reductions (partials are per workgroup)
+    std::atomic<int> reduce_bpc{0};     // workgroups per CU for reductions; 0 = each launch shape's own default (4 x 512 threads)
+    std::atomic<int> reduce_shape{0};   // min_max launch shape A/B (ec_abi.hip launch_min_max): 0 = 512 thr x 8 loads (default)
     std::atomic<int> map_u{2};          // 16-B groups per lane per tile for the map kernels (1, 2 or 4)
     std::atomic<int> peel{1};              // leading-cell peel of the binop/fused kernels: 0 off, 1 for 1-byte operands, 2 also for 2-byte ones
     std::atomic<int> unaligned_vector{1};  // 1 = vector kernels at any cell offset (gfx950 unaligned global access);

@@ -178,6 +178,8 @@ class CellValue:
         if isinstance(x, bool):
             raise TypeError("bool is not a CellEncoding")
         if isinstance(x, int):
+            if not -2**31 <= x < 2**31:  # a Rust integer literal defaults to i32 and does not compile out of range
+                raise OverflowError(f"literal out of range for `i32`: {x} (pass a numpy scalar of the intended type)")
             return CellValue(Int32, x)
         if isinstance(x, float):
             return CellValue(Float64, x)
@@ -355,6 +357,8 @@ class CellBuffer:
     def from_vec(data) -> "CellBuffer":
         a = np.ascontiguousarray(data)
         if a.dtype == np.dtype(np.int64) and not isinstance(data, np.ndarray):
+            if a.size and (a.min() < -2**31 or a.max() >= 2**31):
+                raise OverflowError("literal out of range for `i32` (pass a numpy array of the intended type)")
             a = a.astype(np.int32)  # Rust integer literals default to i32
         return CellBuffer(cell_type_of(a.dtype), a.size, _upload(a.ravel()))
 

@@ -29,10 +29,35 @@ from .buffer import CELL_TYPES, CT_NAMES, NP_DTYPES, CellBuffer, CellValue, Mask
 _CT_BY_NAME = {CT_NAMES[ct]: ct for ct in CELL_TYPES}
 
 
+class _F32(float):
+    """A Float32 cell on its way to JSON: serde_json prints an f32 with the shortest digits that round-trip AS f32
+    (0.1f32 -> `0.1`), not the digits of its f64 widening (0.10000000149011612)."""
+
+
 def _num(x):
     if isinstance(x, float) and not math.isfinite(x):
         return None
     return x
+
+
+def _f32_text(x: float) -> str:
+    v = np.float32(x)
+    ax = abs(float(v))
+    if ax == 0.0 or 1e-5 <= ax < 1e16:  # ryu's plain-decimal range; always with a fractional part
+        return np.format_float_positional(v, unique=True, trim="0")
+    mant, exp = np.format_float_scientific(v, unique=True, trim="-").split("e")
+    return f"{mant}e{int(exp)}"
+
+
+def _emit(x) -> str:
+    """Compact JSON of the small structure to_wire() builds (dict / list / str / bool / None / int / float / _F32)."""
+    if isinstance(x, dict):
+        return "{" + ",".join(json.dumps(k) + ":" + _emit(v) for k, v in x.items()) + "}"
+    if isinstance(x, (list, tuple)):
+        return "[" + ",".join(_emit(v) for v in x) + "]"
+    if isinstance(x, _F32):
+        return _f32_text(x)
+    return json.dumps(x)
 
 
 def cell_type_to_wire(ct: int) -> str:
@@ -48,13 +73,17 @@ def cell_type_from_wire(name: str) -> int:
 def to_wire(x):
     """The JSON-ready structure serde_json would emit for `x`."""
     if isinstance(x, CellBuffer):
-        return {CT_NAMES[x.cell_type()]: [_num(v) for v in x.to_numpy().tolist()]}
+        vals = [_num(v) for v in x.to_numpy().tolist()]
+        if x.cell_type() == CT_NAMES.index("Float32"):
+            vals = [v if v is None else _F32(v) for v in vals]
+        return {CT_NAMES[x.cell_type()]: vals}
     if isinstance(x, Mask):
         return [bool(b) for b in x.to_numpy().tolist()]
     if isinstance(x, MaskedCellBuffer):
         return [to_wire(x.buffer()), to_wire(x.mask())]
     if isinstance(x, CellValue):
-        return {CT_NAMES[x.cell_type()]: _num(x.value.item())}
+        v = _num(x.value.item())
+        return {CT_NAMES[x.cell_type()]: _F32(v) if (v is not None and x.cell_type() == CT_NAMES.index("Float32")) else v}
     if isinstance(x, NoData):
         if x.kind == NoData.NONE:
             return "None"
@@ -120,7 +149,7 @@ def nodata_from_wire(d, ct: int) -> NoData:
 
 
 def dumps(x) -> str:
-    return json.dumps(to_wire(x), separators=(",", ":"))
+    return _emit(to_wire(x))
 
 
 def loads_buffer(s: str) -> CellBuffer:

@@ -167,6 +167,9 @@ def test_serde_wire_shapes_round_trip(ec):
     w = ec.wire
     assert w.dumps(ec.CellBuffer.from_vec(np.array([1, 2, 3], np.uint8))) == '{"UInt8":[1,2,3]}'
     assert w.dumps(ec.CellBuffer.from_vec(np.array([1.5, -2.0], np.float32))) == '{"Float32":[1.5,-2.0]}'
+    # an f32 prints with the shortest digits that round-trip as f32, as serde_json does (not 0.10000000149011612)
+    assert w.dumps(ec.CellBuffer.from_vec(np.array([0.1, 1e20, 3.0e-7], np.float32))) == '{"Float32":[0.1,1e20,3e-7]}'
+    assert w.dumps(ec.CellValue.new(np.float32(0.1))) == '{"Float32":0.1}'
     assert w.dumps(ec.Mask.new([True, False])) == "[true,false]"
     m = ec.MaskedCellBuffer.from_vec_with_nodata(np.array([0, 7, 0, 9], np.uint16), ec.NoData.new(0))
     assert w.dumps(m) == '[{"UInt16":[0,7,0,9]},[false,true,false,true]]'
@@ -190,6 +193,19 @@ def test_serde_wire_shapes_round_trip(ec):
     with pytest.raises(AssertionError):
         w.loads_masked('[{"UInt8":[1,2]},[true]]')  # MaskedCellBuffer::new length assert (masked_buffer.rs:48-53)
     assert w.loads_buffer('{"Int32":[]}').cell_type() == ec.Int32
+
+
+def test_integer_literals_default_to_i32_and_refuse_overflow(ec):
+    """Python ints stand for Rust integer literals, which are i32 unless annotated: out-of-range ones do not compile
+    in Rust and raise here instead of wrapping."""
+    assert ec.CellValue.new(7).cell_type() == ec.Int32
+    assert ec.CellBuffer.from_vec([1, 2, 3]).cell_type() == ec.Int32
+    for bad in (2**31, -2**31 - 1):
+        with pytest.raises(OverflowError):
+            ec.CellValue.new(bad)
+        with pytest.raises(OverflowError):
+            ec.CellBuffer.from_vec([1, bad])
+    assert ec.CellValue.new(np.int64(2**40)).cell_type() == ec.Int64
 
 
 def test_buffer_to_vec(ec):
