@@ -25,6 +25,17 @@ static_assert(kMaxReduceBlocks <= kFinalizeMaxParts, "the finalize kernels read 
 
 static ec_status ensure_init() { return ensure_ready(); }
 
+// Workgroups of `kernel` (BLOCK threads, no dynamic LDS) that fit on one CU at a time, at most `want`.
+template <typename K>
+static int resident_per_cu(K kernel, int block, int want) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        return want;
+    }
+    return nb < want ? nb : want;
+}
+
 // Workgroups a reduction launches at most: `per_cu` per CU (the launch shape's own default: as many as are resident
 // at once, so the grid runs as one round) unless "reduce_bpc" overrides it; never more than the finalize kernels read.
 static int reduce_cap(int per_cu) {
@@ -108,7 +119,11 @@ static ec_status launch_min_max(const void* p, const uint8_t* mask, size_t n, in
             // launch shape: 512 threads x 8 loads in flight by default; "reduce_shape" selects the A/B alternatives
             auto launch = [&](auto u_tag, auto block_tag, int per_cu) {
                 constexpr int U = decltype(u_tag)::value, BLOCK = decltype(block_tag)::value;
-                const int cap2 = reduce_cap(per_cu);
+                // as many workgroups per CU as are resident at once (the masked kernels of some types need more than
+                // 64 VGPRs and fit 3, not 4, of these workgroups on a CU): the grid then runs as ONE round
+                static const int resident[2] = {resident_per_cu(k_min_max_partials<T, false, U, BLOCK>, BLOCK, per_cu),
+                                                resident_per_cu(k_min_max_partials<T, true, U, BLOCK>, BLOCK, per_cu)};
+                const int cap2 = reduce_cap(resident[mask ? 1 : 0]);
                 size_t tiles = (groups + size_t(BLOCK) * U - 1) / (size_t(BLOCK) * U);
                 if (tiles < 1) tiles = 1;
                 grid = static_cast<unsigned>(tiles < size_t(cap2) ? tiles : size_t(cap2));
