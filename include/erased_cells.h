@@ -242,6 +242,8 @@ ec_status ec_shard_group_shard(const ec_shard_group *g, int32_t shard, int32_t *
 /* Runs fn(shard, device, stream, user) once per shard, each on that shard's launch thread with its device current,
  * concurrently; returns when all have returned (the work they enqueued may still be running): the building block
  * with which a host fans out any entry point of this header.  The first failing status is returned. */
+/* (fn must not call ec_shard_group_* / ec_sharded_* of the SAME group — one sharded call runs at a time per group;
+ * destroy every group before ec_shutdown().) */
 typedef ec_status (*ec_shard_fn)(int32_t shard, int32_t device, ec_stream stream, void *user);
 ec_status ec_shard_group_foreach(ec_shard_group *g, ec_shard_fn fn, void *user);
 ec_status ec_shard_group_sync(ec_shard_group *g); /* waits for every shard's stream */

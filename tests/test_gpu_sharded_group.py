@@ -257,3 +257,69 @@ def test_host_threads_sharing_one_stream_take_turns(ec):
     [t.join() for t in ts]
     assert not errors, errors[:3]
     chk(L.ec_stream_destroy(s))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_shard_group_property_any_shape_any_shard_count(ec):
+    """Property test (hypothesis): any raster shape (ragged, fewer rows than shards, empty), shard count, cell type
+    and mask gives the whole raster's answers — scatter/gather round trip, per-shard divide, min_max (masked and
+    not) and counts, against the oracle on the unsharded data."""
+    import os
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    from erased_cells_hip import sharded
+    from vectors import bits_of, rand_cells, rand_mask
+    L, chk = ec.lib(), ec._ffi.check
+    groups = {}
+    try:
+        for G in (1, 2, 3, 8):
+            g = C.c_void_p()
+            chk(L.ec_shard_group_create((C.c_int32 * G)(*([0] * G)), G, 1, C.byref(g)))
+            groups[G] = g
+        pool = {ct: rand_cells(ct, 40000, 700 + ct) for ct in range(eco.NTYPES)}
+        mpool = rand_mask(40000, 77)
+
+        @settings(max_examples=int(os.environ.get("EC_PROP_EXAMPLES", "120")), deadline=None, suppress_health_check=list(HealthCheck))
+        @given(G=st.sampled_from([1, 2, 3, 8]), rows=st.integers(0, 40), cols=st.sampled_from([0, 1, 7, 64, 333, 1000]),
+               ct=st.integers(0, eco.NTYPES - 1), rt=st.integers(0, eco.NTYPES - 1), off=st.integers(0, 37), masked=st.booleans())
+        def prop(G, rows, cols, ct, rt, off, masked):
+            n = rows * cols
+            a, b, m = pool[ct][off:off + n], pool[rt][off + 1:off + 1 + n], mpool[off:off + n]
+            grp = groups[G]
+            rng = [sharded.shard_range(rows, cols, g, G) for g in range(G)]
+            assert sum(r[1] for r in rng) == n and all(rng[i][0] + rng[i][1] == rng[i + 1][0] for i in range(G - 1))
+            lens = (C.c_size_t * G)(*[r[1] for r in rng])
+            sa, sb = a.dtype.itemsize, b.dtype.itemsize
+
+            def sizes(sz):
+                return (C.c_size_t * G)(*[r[1] * sz for r in rng]), (C.c_size_t * G)(*[r[0] * sz for r in rng])
+
+            (ba, oa), (bb, ob), (b8, o8), (b1, o1) = sizes(sa), sizes(sb), sizes(8), sizes(1)
+            da, db, dq, dm = (C.c_void_p * G)(), (C.c_void_p * G)(), (C.c_void_p * G)(), (C.c_void_p * G)()
+            for d, bts in ((da, ba), (db, bb), (dq, b8), (dm, b1)):
+                chk(L.ec_sharded_alloc(grp, bts, d))
+            try:
+                aa, bb_, mm = np.ascontiguousarray(a), np.ascontiguousarray(b), np.ascontiguousarray(m)
+                chk(L.ec_sharded_upload(grp, da, aa.ctypes.data_as(C.c_void_p), oa, ba))
+                chk(L.ec_sharded_upload(grp, db, bb_.ctypes.data_as(C.c_void_p), ob, bb))
+                chk(L.ec_sharded_upload(grp, dm, mm.ctypes.data_as(C.c_void_p), o1, b1))
+                chk(L.ec_sharded_binop(grp, ec.DIV, ct, da, rt, db, lens, dq))
+                q = np.empty(n, np.float64)
+                chk(L.ec_sharded_download(grp, q.ctypes.data_as(C.c_void_p), dq, o8, b8))
+                from vectors import assert_f64_bits_equal
+                assert_f64_bits_equal(q, eco.f_binop(eco.DIV, aa, bb_))
+                mn, mx = ec._ffi.EcValue(), ec._ffi.EcValue()
+                chk(L.ec_sharded_min_max(grp, ct, da, dm if masked else None, lens, C.byref(mn), C.byref(mx)))
+                emn, emx = eco.f_min_max(aa, mm if masked else None)
+                assert (ec.CellValue.from_ec(mn).bits(), ec.CellValue.from_ec(mx).bits()) == (emn.bits(), emx.bits())
+                t, f = C.c_uint64(), C.c_uint64()
+                chk(L.ec_sharded_counts(grp, dm, lens, C.byref(t), C.byref(f)))
+                assert (t.value, f.value) == eco.mask_counts(mm)
+            finally:
+                for d in (da, db, dq, dm):
+                    chk(L.ec_sharded_free(grp, d))
+
+        prop()
+    finally:
+        for g in groups.values():
+            chk(L.ec_shard_group_destroy(g))

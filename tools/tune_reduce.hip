@@ -113,6 +113,22 @@ __global__ __launch_bounds__(1024) void k_finalize(const uint64_t* __restrict__ 
     if (threadIdx.x == 0) out[0] = c;
 }
 
+// finalize with BLOCK threads, every thread's PER loads in flight before the first add
+template <int BLOCK, int PER>
+__global__ __launch_bounds__(BLOCK) void k_finalize_b(const uint64_t* __restrict__ partials, int nparts, uint64_t* out) {
+    uint64_t v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = threadIdx.x + j * BLOCK;
+        v[j] = i < nparts ? partials[i] : 0ull;
+    }
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) c += v[j];
+    c = block_sum<BLOCK>(c);
+    if (threadIdx.x == 0) out[0] = c;
+}
+
 // single launch
 template <int BLOCK, int U, int FOLD_PER>
 __global__ __launch_bounds__(BLOCK) void k_single(const uint8_t* m, size_t n, uint64_t* partials, unsigned* ticket, uint64_t* out) {
@@ -167,6 +183,12 @@ static size_t tiles_of(size_t n, size_t tile_groups) { return (n / 16 + tile_gro
          k_partials<BLOCK, U, FAST><<<g, BLOCK>>>(m, n, p);                                                     \
          k_finalize<4><<<1, 1024>>>(p, g, o);                                                                   \
      }}
+#define TWOF(NAME, FB, FPER)                                                                                    \
+    {NAME, [](const uint8_t* m, size_t n, uint64_t* p, unsigned*, uint64_t* o) {                                \
+         const int g = (int)std::min<size_t>(1024, tiles_of(n, size_t(512) * 8));                              \
+         k_partials<512, 8, true><<<g, 512>>>(m, n, p);                                                         \
+         k_finalize_b<FB, FPER><<<1, FB>>>(p, g, o);                                                            \
+     }}
 #define TILE(NAME, BLOCK, U)                                                                                    \
     {NAME, [](const uint8_t* m, size_t n, uint64_t* p, unsigned*, uint64_t* o) {                                \
          const int g = (int)tiles_of(n, size_t(BLOCK) * U);                                                     \
@@ -202,6 +224,10 @@ int main(int argc, char** argv) {
         TWO("A2  2 launches 512thr U8 fast cap1024", 512, 8, true, 1024),
         TWO("A2  2 launches 1024thr U8 fast cap256", 1024, 8, true, 256),
         TWO("A2  2 launches 1024thr U8 fast cap512", 1024, 8, true, 512),
+        TWOF("F   512thr U8 cap1024 + finalize 64 thr x16", 64, 16),
+        TWOF("F   512thr U8 cap1024 + finalize 128 thr x8", 128, 8),
+        TWOF("F   512thr U8 cap1024 + finalize 256 thr x4", 256, 4),
+        TWOF("F   512thr U8 cap1024 + finalize 512 thr x2", 512, 2),
         TILE("A3  2 launches tile/WG 256thr U8", 256, 8),
         TILE("A3  2 launches tile/WG 256thr U16", 256, 16),
         TILE("A3  2 launches tile/WG 512thr U16", 512, 16),
@@ -225,7 +251,7 @@ int main(int argc, char** argv) {
     const int iters = 400;
     for (int r = 0; r < rounds; ++r) {
         for (int k = 0; k < nv; ++k) {
-            const int v = (k * 7 + r * 3) % nv;  // a different order every round (nv = 19 is prime to 7)
+            const int v = (k * 7 + r * 3) % nv;  // a different order every round (nv = 23 is prime to 7)
             for (int i = 0; i < 200; ++i) vs[v].run(m, n, partials, ticket, out);  // clocks up, caches in steady state
             CK(hipMemsetAsync(out, 0, 8));
             CK(hipEventRecord(e0));
