@@ -230,6 +230,8 @@ extern "C" ec_status ec_get_device(int32_t* device) {
 
 extern "C" ec_status ec_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
+    int before = -1;
+    const bool had = !g_devs.empty() && hipGetDevice(&before) == hipSuccess;
     for (auto& kv : g_devs) {
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
@@ -240,6 +242,7 @@ extern "C" ec_status ec_shutdown(void) {
             (void)hipMemPoolDestroy(kv.second.pool);
         }
     }
+    if (had) (void)hipSetDevice(before);  // the caller's HIP device is left as it was
     (void)hipGetLastError();
     g_devs.clear();
     g_default_device.store(-1);
