@@ -76,3 +76,120 @@ def allreduce_keys_host(keys2, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return int(t[0]), int(t[1])
+
+
+# --------------------------------------------------------------------------- one process, all GPUs
+class ShardedBuffer:
+    """A raster cut into row-blocks, block i in device i's HBM (cells of one type, or a mask with ct = UInt8)."""
+
+    def __init__(self, group: "ShardGroup", ct: int, ptrs, lens):
+        self.group, self.ct, self.ptrs, self.lens = group, ct, ptrs, list(lens)
+
+    def len(self) -> int:
+        return sum(self.lens)
+
+    def free(self) -> None:
+        if self.ptrs is not None:
+            check(lib().ec_sharded_free(self.group.handle, self.ptrs))
+            self.ptrs = None
+
+
+class ShardGroup:
+    """`ec_shard_group`: one process driving the listed GPUs — per device a launch thread, a stream and a communicator
+    of the clique inside the library.  `host_combine=True` folds the 16-byte reduction payloads on the host instead of
+    over xGMI (no RCCL; lets one device be listed several times, e.g. to rehearse on a 1-GPU box)."""
+
+    def __init__(self, devices, host_combine: bool = False):
+        self.n = len(devices)
+        self.handle = C.c_void_p()
+        arr = (C.c_int32 * self.n)(*devices)
+        check(lib().ec_shard_group_create(arr, self.n, 1 if host_combine else 0, C.byref(self.handle)))
+
+    def close(self) -> None:
+        if self.handle:
+            check(lib().ec_shard_group_destroy(self.handle))
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def shard(self, i: int):
+        dev, st = C.c_int32(), C.c_void_p()
+        check(lib().ec_shard_group_shard(self.handle, i, C.byref(dev), C.byref(st)))
+        return dev.value, st.value
+
+    def sync(self) -> None:
+        check(lib().ec_shard_group_sync(self.handle))
+
+    def foreach(self, fn) -> None:
+        """fn(shard, device, stream) on every shard's own launch thread (its device current); any ABI call may be made
+        there on `stream`.  An exception raised by fn is re-raised here."""
+        from ._ffi import SHARD_FN, EC_ERR_ARG
+        raised = []
+
+        def tramp(shard, device, stream, _user):
+            try:
+                fn(shard, device, stream)
+                return 0
+            except Exception as e:  # noqa: BLE001 — carried across the C frame
+                raised.append(e)
+                return EC_ERR_ARG
+
+        cb = SHARD_FN(tramp)
+        st = lib().ec_shard_group_foreach(self.handle, cb, None)
+        if raised:
+            raise raised[0]
+        check(st)
+
+    def _sizes(self, lens, itemsize):
+        return (C.c_size_t * self.n)(*[ln * itemsize for ln in lens])
+
+    def alloc(self, ct: int, lens) -> ShardedBuffer:
+        ptrs = (C.c_void_p * self.n)()
+        check(lib().ec_sharded_alloc(self.handle, self._sizes(lens, B.NP_DTYPES[ct].itemsize), ptrs))
+        return ShardedBuffer(self, ct, ptrs, lens)
+
+    def scatter(self, a, n_rows: int, n_cols: int, ct: int = None) -> ShardedBuffer:
+        """`From<Vec<T>>` of a row-major raster: contiguous row-blocks, block i to device i."""
+        import numpy as np
+        a = np.ascontiguousarray(a).ravel()
+        assert a.size == n_rows * n_cols
+        ct = B.cell_type_of(a.dtype) if ct is None else ct
+        rng = [shard_range(n_rows, n_cols, g, self.n) for g in range(self.n)]
+        out = self.alloc(ct, [r[1] for r in rng])
+        sz = a.dtype.itemsize
+        offs = (C.c_size_t * self.n)(*[r[0] * sz for r in rng])
+        check(lib().ec_sharded_upload(self.handle, out.ptrs, a.ctypes.data_as(C.c_void_p), offs, self._sizes(out.lens, sz)))
+        return out
+
+    def gather(self, sb: ShardedBuffer):
+        import numpy as np
+        dt = B.NP_DTYPES[sb.ct]
+        out = np.empty(sb.len(), dtype=dt)
+        offs, acc = [], 0
+        for ln in sb.lens:
+            offs.append(acc * dt.itemsize)
+            acc += ln
+        check(lib().ec_sharded_download(self.handle, out.ctypes.data_as(C.c_void_p), sb.ptrs, (C.c_size_t * self.n)(*offs),
+                                        self._sizes(sb.lens, dt.itemsize)))
+        return out
+
+    def binop(self, op: int, l: ShardedBuffer, r: ShardedBuffer) -> ShardedBuffer:
+        assert l.lens == r.lens, "operands must be sharded identically"
+        out = self.alloc(B.Float64, l.lens)
+        check(lib().ec_sharded_binop(self.handle, op, l.ct, l.ptrs, r.ct, r.ptrs, (C.c_size_t * self.n)(*l.lens), out.ptrs))
+        return out
+
+    def min_max(self, sb: ShardedBuffer, mask: ShardedBuffer = None):
+        mn, mx = EcValue(), EcValue()
+        check(lib().ec_sharded_min_max(self.handle, sb.ct, sb.ptrs, mask.ptrs if mask is not None else None,
+                                       (C.c_size_t * self.n)(*sb.lens), C.byref(mn), C.byref(mx)))
+        return B.CellValue.from_ec(mn), B.CellValue.from_ec(mx)
+
+    def counts(self, mask: ShardedBuffer) -> tuple[int, int]:
+        t, f = C.c_uint64(), C.c_uint64()
+        check(lib().ec_sharded_counts(self.handle, mask.ptrs, (C.c_size_t * self.n)(*mask.lens), C.byref(t), C.byref(f)))
+        return t.value, f.value

@@ -323,3 +323,53 @@ def test_shard_group_property_any_shape_any_shard_count(ec):
     finally:
         for g in groups.values():
             chk(L.ec_shard_group_destroy(g))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [1, 3, 8])
+def test_config5_ndvi_in_one_process_over_a_shard_group(ec, golden_dir, G):
+    """BASELINE config 5 from ONE process: the reference's GDAL test (src/gdal/rasterband.rs:166-191) on its own
+    fixtures — bands scattered as row-blocks over the group's devices (169 rows over 8 shards: 22, 21 x 7), nodata
+    masks, u16 -> f32 convert and the fused NDVI fanned out per shard with ec_shard_group_foreach (no communication),
+    then data/nodata counts and min/max through the sharded reductions; the reference's known answers."""
+    from erased_cells_hip import raster, sharded
+    L, chk = ec.lib(), ec._ffi.check
+    red_rb = raster.RasterBand.open(os.path.join(golden_dir, "L8-Elkton-VA-B4.tiff"))
+    nir_rb = raster.RasterBand.open(os.path.join(golden_dir, "L8-Elkton-VA-B5-nd.tiff"))
+    cols, rows = red_rb.size()
+    red_h, nir_h = red_rb.cells, nir_rb.cells
+    assert red_rb.no_data_value() == 0.0 and nir_rb.no_data_value() == 0.0  # GDAL_NODATA = "0" on both fixtures
+    with sharded.ShardGroup([0] * G, host_combine=G > 1) as g:
+        red, nir = g.scatter(red_h, rows, cols), g.scatter(nir_h, rows, cols)
+        if G == 8:
+            assert [ln // cols for ln in red.lens] == [22, 21, 21, 21, 21, 21, 21, 21]
+        lens = red.lens
+        red_f, nir_f = g.alloc(ec.Float32, lens), g.alloc(ec.Float32, lens)
+        red_m, nir_m, out_m = g.alloc(ec.UInt8, lens), g.alloc(ec.UInt8, lens), g.alloc(ec.UInt8, lens)
+        out = g.alloc(ec.Float64, lens)
+        nd = ec.CellValue(ec.UInt16, 0).to_ec()
+
+        def per_shard(i, device, stream):
+            n = lens[i]
+            chk(L.ec_mask_from_nodata(ec.UInt16, red.ptrs[i], n, C.byref(nd), red_m.ptrs[i], stream))
+            chk(L.ec_mask_from_nodata(ec.UInt16, nir.ptrs[i], n, C.byref(nd), nir_m.ptrs[i], stream))
+            chk(L.ec_convert(ec.UInt16, red.ptrs[i], ec.Float32, red_f.ptrs[i], n, stream))
+            chk(L.ec_convert(ec.UInt16, nir.ptrs[i], ec.Float32, nir_f.ptrs[i], n, stream))
+            dt = (C.c_uint8 * 4)(ec.Float32, ec.Float32, ec.Float32, ec.Float32)
+            p = (C.c_void_p * 4)(nir_f.ptrs[i], red_f.ptrs[i], nir_f.ptrs[i], red_f.ptrs[i])
+            m = (C.c_void_p * 4)(nir_m.ptrs[i], red_m.ptrs[i], nir_m.ptrs[i], red_m.ptrs[i])
+            chk(L.ec_masked_fused(ec.SUB, ec.DIV, ec.ADD, dt, p, m, None, n, out.ptrs[i], out_m.ptrs[i], stream))
+
+        g.foreach(per_shard)
+        assert g.counts(out_m) == (31430, 4)                                  # rasterband.rs:180-183
+        mn, mx = g.min_max(out, out_m)
+        assert float(mn.value).hex() == "-0x1.ff8ca5bcc77dcp-4" and float(mx.value).hex() == "0x1.5708125b0ed28p-1"
+        # and cell for cell against the oracle's chain on the whole raster
+        e = eco.f_binop(eco.DIV, eco.f_binop(eco.SUB, eco.f_convert(nir_h.ravel(), eco.F32), eco.f_convert(red_h.ravel(), eco.F32)),
+                        eco.f_binop(eco.ADD, eco.f_convert(nir_h.ravel(), eco.F32), eco.f_convert(red_h.ravel(), eco.F32)))
+        from vectors import assert_f64_bits_equal
+        assert_f64_bits_equal(g.gather(out), e)
+        with pytest.raises(ZeroDivisionError):
+            g.foreach(lambda i, d, s: 1 // 0)                                 # a failing shard function surfaces here
+        for b in (red, nir, red_f, nir_f, red_m, nir_m, out_m, out):
+            b.free()
