@@ -359,14 +359,25 @@ __global__ __launch_bounds__(kRBlock) void k_first_diff_partials(const W* __rest
         const WV* __restrict__ rv = reinterpret_cast<const WV*>(r);
         for (size_t tile = blockIdx.x; tile < ntiles && first == ~0ull; tile += gridDim.x) {
             const size_t base = tile * TILE + threadIdx.x;
+            auto compare = [&](size_t g, const WV& a, const WV& b) {
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const size_t g = base + size_t(j) * kRBlock;
-                if (g < ngroups) {
-                    const WV a = nt_load(lv + g), b = nt_load(rv + g);
+                for (int k = CPL - 1; k >= 0; --k)
+                    if (a[k] != b[k]) { const uint64_t i = head + g * CPL + k; first = i < first ? i : first; }
+            };
+            if (tile * TILE + TILE <= ngroups) {  // full tile: all 2 x U loads in flight before the first compare
+                WV a[U], b[U];
 #pragma unroll
-                    for (int k = CPL - 1; k >= 0; --k)
-                        if (a[k] != b[k]) { const uint64_t i = head + g * CPL + k; first = i < first ? i : first; }
+                for (int j = 0; j < U; ++j) {
+                    a[j] = nt_load(lv + base + size_t(j) * kRBlock);
+                    b[j] = nt_load(rv + base + size_t(j) * kRBlock);
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) compare(base + size_t(j) * kRBlock, a[j], b[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const size_t g = base + size_t(j) * kRBlock;
+                    if (g < ngroups) compare(g, nt_load(lv + g), nt_load(rv + g));
                 }
             }
         }

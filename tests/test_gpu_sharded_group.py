@@ -276,8 +276,8 @@ def test_shard_group_property_any_shape_any_shard_count(ec):
             g = C.c_void_p()
             chk(L.ec_shard_group_create((C.c_int32 * G)(*([0] * G)), G, 1, C.byref(g)))
             groups[G] = g
-        pool = {ct: rand_cells(ct, 40000, 700 + ct) for ct in range(eco.NTYPES)}
-        mpool = rand_mask(40000, 77)
+        pool = {ct: rand_cells(ct, 40000 + 64, 700 + ct) for ct in range(eco.NTYPES)}  # 40 x 1000 cells + the largest offset
+        mpool = rand_mask(40000 + 64, 77)
 
         @settings(max_examples=int(os.environ.get("EC_PROP_EXAMPLES", "120")), deadline=None, suppress_health_check=list(HealthCheck))
         @given(G=st.sampled_from([1, 2, 3, 8]), rows=st.integers(0, 40), cols=st.sampled_from([0, 1, 7, 64, 333, 1000]),
@@ -285,6 +285,7 @@ def test_shard_group_property_any_shape_any_shard_count(ec):
         def prop(G, rows, cols, ct, rt, off, masked):
             n = rows * cols
             a, b, m = pool[ct][off:off + n], pool[rt][off + 1:off + 1 + n], mpool[off:off + n]
+            assert a.size == b.size == m.size == n
             grp = groups[G]
             rng = [sharded.shard_range(rows, cols, g, G) for g in range(G)]
             assert sum(r[1] for r in rng) == n and all(rng[i][0] + rng[i][1] == rng[i + 1][0] for i in range(G - 1))

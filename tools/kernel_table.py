@@ -140,6 +140,15 @@ def main():
     bench("min_max UInt16 masked", 2 + 1, lambda: chk(L.ec_min_max_keys(ec.UInt16, u16.mem.ptr, ma.mem.ptr, n, keys.data_ptr(), stream)))
     bench("min_max Float32 masked", 4 + 1, lambda: chk(L.ec_min_max_keys(ec.Float32, a.mem.ptr, ma.mem.ptr, n, keys.data_ptr(), stream)))
 
+    # ---- Ord / Eq: full scan of two equal buffers (the worst case; synchronous result, so the time includes the wait)
+    idx = C.c_uint64()
+    f64b = ec.CellBuffer.empty(n, ec.Float64)
+    chk(L.ec_copy(f64b.mem.ptr, f64.mem.ptr, 8 * n, stream))
+    bench("first_difference Float64 (equal buffers)", 16, lambda: chk(L.ec_first_difference(ec.Float64, f64.mem.ptr, f64b.mem.ptr, n, C.byref(idx), stream)))
+    u8b = ec.CellBuffer.empty(n, ec.UInt8)
+    chk(L.ec_copy(u8b.mem.ptr, u8.mem.ptr, n, stream))
+    bench("first_difference UInt8 (equal buffers)", 2, lambda: chk(L.ec_first_difference(ec.UInt8, u8.mem.ptr, u8b.mem.ptr, n, C.byref(idx), stream)))
+    del f64b, u8b
     # ---- fused chains
     dt4 = (C.c_uint8 * 4)(ec.UInt16, ec.UInt16, ec.UInt16, ec.UInt16)
     u16b = synth(ec.UInt16, 17, 1, 30000)
