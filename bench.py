@@ -185,7 +185,7 @@ def recorded_traffic(cells_per_launch: int):
     return None, None
 
 
-def verify_slices(workload: str, env: dict, cells: int = 1 << 20):
+def verify_slices(env: dict, cells: int = 1 << 20):
     """Bit-exact check of the timed output against numpy's IEEE f64 divide on slices at both ends of the shard."""
     import numpy as np
     a, b, out, n = env["a"], env["b"], env["out"], env["n"]
@@ -419,7 +419,7 @@ def main():
     # ---- the timed output is checked, outside `value`: a slice at each end of this rank's shard against
     # numpy's IEEE f64 arithmetic on the same operands (the oracle itself checks it in the cpu_baseline leg)
     scope = dict(a=a, b=b, out=out, n=n) if args.workload == "div_u8_u16" else None
-    verified = verify_slices(args.workload, scope) if scope else None
+    verified = verify_slices(scope) if scope else None
 
     # per-rank record -> every rank: [elapsed s, device ms, cells, verified]
     mine = torch.tensor([elapsed, dev_ms, float(n), 1.0 if verified in (None, True) else 0.0], dtype=torch.float64)
