@@ -58,7 +58,8 @@ static bool try_fused_mixed(FusedArgs& fa, int nops, size_t n, double* out, uint
                     c1 += peel_cost(fa.p[k], ecl::size_of(fa.dt[k]), 1);
                 }
             fa.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
-            const size_t per_tile = size_t(kBlock) * kFusedU;
+            const size_t sa = ecl::size_of(A), sb = ecl::size_of(B);
+            const size_t per_tile = size_t(kBlock) * fused_u(sa > sb ? sa : sb);
             const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
             switch (fa.o2) {
                 case EC_ADD: return dispatch_fused_mixed<EC_ADD>(fa, pair, pat, grid, out, out_mask, n, s);
@@ -151,7 +152,7 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         for (int k = 0; k < 4; ++k)
             if (!fa.is_sc[k] && fa.alias[k] == k) { c0 += peel_cost(fa.p[k], ecl::size_of(u), 0); c1 += peel_cost(fa.p[k], ecl::size_of(u), 1); }
         fa.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
-        const size_t per_tile = size_t(kBlock) * kFusedU;
+        const size_t per_tile = size_t(kBlock) * fused_u(ecl::size_of(u));
         const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
         switch (o2) {
             case EC_ADD: dispatch_fused<EC_ADD>(fa, u, grid, out, out_mask, n, s); break;

@@ -96,7 +96,15 @@ __device__ __forceinline__ double ndvi_shape_small_int(double x, double y, doubl
     return div_small_int(t1, t2);
 }
 
-constexpr int kFusedU = 4;  // pairs per lane per tile: the fused kernels carry more per-lane setup than k_binop_direct
+// Pairs per lane per tile.  The right depth follows the operand width (tools/tune_fused2.hip, profiles/r02/
+// tune_fused2.log): 1- and 2-byte cells want 4 (NDVI u16: 0.774 of peak at 4, 0.727 at 2, 0.750 at 8), 4- and
+// 8-byte cells want 2 ((a+b)*c on f32 with masks: 0.794 at 2, 0.777 at 4, 0.774 at 8) — about the same bytes in
+// flight per lane either way.  EC_FUSED_U forces one depth for every type (the tuner's builds).
+#ifdef EC_FUSED_U
+constexpr int fused_u(size_t) { return EC_FUSED_U; }
+#else
+constexpr int fused_u(size_t widest_cell_bytes) { return widest_cell_bytes >= 4 ? 2 : 4; }
+#endif
 
 // mask phase: AND of the distinct operand masks (src/masked/masked_buffer.rs:333 applied per step),
 // 16 mask bytes per lane
@@ -120,11 +128,12 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
 }
 
 
-// One workgroup per tile of kBlock*kFusedU pairs, two-front order, as k_binop_direct.  All buffer
+// One workgroup per tile of kBlock*fused_u(sizeof T) pairs, two-front order, as k_binop_direct.  All buffer
 // operands have cell type T.
 template <typename T, int O1, int O2, int O3>
 __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
     using T2 = vec<T, 2>;
+    constexpr int kFusedU = fused_u(sizeof(T));
     const unsigned head = fa.head;
     const size_t npairs = (n - head) >> 1;
     constexpr size_t TILE = size_t(kBlock) * kFusedU;
