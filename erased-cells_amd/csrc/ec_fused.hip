@@ -59,7 +59,7 @@ static bool try_fused_mixed(FusedArgs& fa, int nops, size_t n, double* out, uint
                 }
             fa.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
             const size_t sa = ecl::size_of(A), sb = ecl::size_of(B);
-            const size_t per_tile = size_t(kBlock) * fused_u(sa > sb ? sa : sb);
+            const size_t per_tile = size_t(kBlock) * fused_u(sa < sb ? sa : sb);
             const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
             switch (fa.o2) {
                 case EC_ADD: return dispatch_fused_mixed<EC_ADD>(fa, pair, pat, grid, out, out_mask, n, s);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_mixed(FusedArgs fa, double* __
     using Y2 = vec<TY, 2>;
     using Z2 = vec<TZ, 2>;
     using W2 = vec<TW, 2>;
-    constexpr int kFusedU = fused_u(sizeof(A) > sizeof(B) ? sizeof(A) : sizeof(B));
+    constexpr int kFusedU = fused_u(sizeof(A) < sizeof(B) ? sizeof(A) : sizeof(B));  // by the NARROWER type: u16 + f32 runs the same at 2 and 4, f32 + f64 wants 2
     const unsigned head = fa.head;
     const size_t npairs = (n - head) >> 1;
     constexpr size_t TILE = size_t(kBlock) * kFusedU;
