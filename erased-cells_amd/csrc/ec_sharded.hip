@@ -305,6 +305,58 @@ extern "C" ec_status ec_sharded_binop(ec_shard_group* g, ec_op op, ec_dtype lt, 
     return for_each_shard(g, [&](int i) { return ec_binop(op, lt, l[i], rt, r[i], n[i], out[i], g->streams[i]); });
 }
 
+extern "C" ec_status ec_sharded_masked_binop(ec_shard_group* g, ec_op op, ec_dtype lt, const void* const* l, const uint8_t* const* lmask,
+                                             ec_dtype rt, const void* const* r, const uint8_t* const* rmask, const size_t* n,
+                                             double* const* out, uint8_t* const* out_mask) {
+    ec_status st = check_group(g, "ec_sharded_masked_binop");
+    if (st != EC_OK) return st;
+    if (!l || !lmask || !r || !rmask || !n || !out || !out_mask) return set_error(EC_ERR_ARG, "ec_sharded_masked_binop: null argument");
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    return for_each_shard(g, [&](int i) {
+        return ec_masked_binop(op, lt, l[i], lmask[i], rt, r[i], rmask[i], n[i], out[i], out_mask[i], g->streams[i]);
+    });
+}
+
+extern "C" ec_status ec_sharded_convert(ec_shard_group* g, ec_dtype st_, const void* const* src, ec_dtype dt, void* const* dst,
+                                        const size_t* n) {
+    ec_status st = check_group(g, "ec_sharded_convert");
+    if (st != EC_OK) return st;
+    if (!ec_can_fit_into(st_, dt)) return ec_convert(st_, nullptr, dt, nullptr, 0, nullptr);  // EC_ERR_NARROWING, before any device work
+    if (!src || !dst || !n) return set_error(EC_ERR_ARG, "ec_sharded_convert: null argument");
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    return for_each_shard(g, [&](int i) { return ec_convert(st_, src[i], dt, dst[i], n[i], g->streams[i]); });
+}
+
+extern "C" ec_status ec_sharded_mask_from_nodata(ec_shard_group* g, ec_dtype t, const void* const* p, const size_t* n,
+                                                 const ec_value* nd_or_null, uint8_t* const* mask) {
+    ec_status st = check_group(g, "ec_sharded_mask_from_nodata");
+    if (st != EC_OK) return st;
+    if (!p || !n || !mask) return set_error(EC_ERR_ARG, "ec_sharded_mask_from_nodata: null argument");
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    return for_each_shard(g, [&](int i) { return ec_mask_from_nodata(t, p[i], n[i], nd_or_null, mask[i], g->streams[i]); });
+}
+
+extern "C" ec_status ec_sharded_fused(ec_shard_group* g, ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void* const* const p[4],
+                                      const uint8_t* const* const masks_or_null[4], const ec_value* scalars_or_null, const size_t* n,
+                                      double* const* out, uint8_t* const* out_mask_or_null) {
+    ec_status st = check_group(g, "ec_sharded_fused");
+    if (st != EC_OK) return st;
+    if (!dt || !p || !n || !out) return set_error(EC_ERR_ARG, "ec_sharded_fused: null argument");
+    if ((masks_or_null != nullptr) != (out_mask_or_null != nullptr))
+        return set_error(EC_ERR_ARG, "ec_sharded_fused: masks and out_mask go together");
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    return for_each_shard(g, [&](int i) {
+        const void* pi[4];
+        const uint8_t* mi[4];
+        for (int k = 0; k < 4; ++k) {
+            pi[k] = p[k] ? p[k][i] : nullptr;  // p[k] == NULL: operand k is the scalar scalars[k]
+            mi[k] = (masks_or_null && masks_or_null[k]) ? masks_or_null[k][i] : nullptr;
+        }
+        if (masks_or_null) return ec_masked_fused(o1, o2, o3, dt, pi, mi, scalars_or_null, n[i], out[i], out_mask_or_null[i], g->streams[i]);
+        return ec_fused(o1, o2, o3, dt, pi, scalars_or_null, n[i], out[i], g->streams[i]);
+    });
+}
+
 extern "C" ec_status ec_sharded_min_max(ec_shard_group* g, ec_dtype t, const void* const* p, const uint8_t* const* masks_or_null,
                                         const size_t* n, ec_value* mn, ec_value* mx) {
     ec_status st = check_group(g, "ec_sharded_min_max");

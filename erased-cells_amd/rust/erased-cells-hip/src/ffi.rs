@@ -133,6 +133,17 @@ extern "C" {
                                byte_offsets: *const usize, bytes: *const usize) -> ec_status;
     pub fn ec_sharded_binop(g: *mut ec_shard_group, op: ec_op, lt: ec_dtype, l: *const *const c_void, rt: ec_dtype,
                             r: *const *const c_void, n: *const usize, out: *const *mut f64) -> ec_status;
+    pub fn ec_sharded_masked_binop(g: *mut ec_shard_group, op: ec_op, lt: ec_dtype, l: *const *const c_void,
+                                   lmask: *const *const u8, rt: ec_dtype, r: *const *const c_void, rmask: *const *const u8,
+                                   n: *const usize, out: *const *mut f64, out_mask: *const *mut u8) -> ec_status;
+    pub fn ec_sharded_convert(g: *mut ec_shard_group, st: ec_dtype, src: *const *const c_void, dt: ec_dtype,
+                              dst: *const *mut c_void, n: *const usize) -> ec_status;
+    pub fn ec_sharded_mask_from_nodata(g: *mut ec_shard_group, t: ec_dtype, p: *const *const c_void, n: *const usize,
+                                       nd_or_null: *const ec_value, mask: *const *mut u8) -> ec_status;
+    pub fn ec_sharded_fused(g: *mut ec_shard_group, o1: ec_op, o2: ec_op, o3: ec_op, dt: *const ec_dtype,
+                            p: *const *const *const c_void, masks_or_null: *const *const *const u8,
+                            scalars_or_null: *const ec_value, n: *const usize, out: *const *mut f64,
+                            out_mask_or_null: *const *mut u8) -> ec_status;
     pub fn ec_sharded_min_max(g: *mut ec_shard_group, t: ec_dtype, p: *const *const c_void,
                               masks_or_null: *const *const u8, n: *const usize, mn: *mut ec_value,
                               mx: *mut ec_value) -> ec_status;

@@ -258,6 +258,23 @@ ec_status ec_sharded_download(ec_shard_group *g, void *dst_host, const void *con
 /* impl {Add,Sub,Mul,Div} for &CellBuffer (src/buffer.rs:324-329) on every shard; asynchronous, no communication. */
 ec_status ec_sharded_binop(ec_shard_group *g, ec_op op, ec_dtype lt, const void *const *l, ec_dtype rt,
                            const void *const *r, const size_t *n, double *const *out);
+/* The other element-wise entry points on every shard, same arguments as their one-GPU forms with one pointer per
+ * shard: impl $trt for &MaskedCellBuffer (src/masked/masked_buffer.rs:326-335), BufferOps::convert
+ * (src/buffer.rs:150-167; EC_ERR_NARROWING before any device work), from_vec_with_nodata
+ * (src/masked/masked_buffer.rs:62-71), and the fused chains — p[k] is operand k's per-shard pointer array, or NULL
+ * for a scalar operand (scalars[k]); masks_or_null / out_mask_or_null both given or both NULL.  Asynchronous. */
+ec_status ec_sharded_masked_binop(ec_shard_group *g, ec_op op, ec_dtype lt, const void *const *l,
+                                  const uint8_t *const *lmask, ec_dtype rt, const void *const *r,
+                                  const uint8_t *const *rmask, const size_t *n, double *const *out,
+                                  uint8_t *const *out_mask);
+ec_status ec_sharded_convert(ec_shard_group *g, ec_dtype st, const void *const *src, ec_dtype dt, void *const *dst,
+                             const size_t *n);
+ec_status ec_sharded_mask_from_nodata(ec_shard_group *g, ec_dtype t, const void *const *p, const size_t *n,
+                                      const ec_value *nd_or_null, uint8_t *const *mask);
+ec_status ec_sharded_fused(ec_shard_group *g, ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4],
+                           const void *const *const p[4], const uint8_t *const *const masks_or_null[4],
+                           const ec_value *scalars_or_null, const size_t *n, double *const *out,
+                           uint8_t *const *out_mask_or_null);
 /* BufferOps::min_max (src/buffer.rs:169-173; masked: src/masked/masked_buffer.rs:208-217) of the whole raster:
  * ec_min_max_keys per shard, one all-reduce(MAX) of the 16-byte keys, decode.  masks_or_null == NULL: unmasked.
  * Synchronous result. */

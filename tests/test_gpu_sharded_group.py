@@ -363,6 +363,34 @@ def test_config5_ndvi_in_one_process_over_a_shard_group(ec, golden_dir, G):
 
         g.foreach(per_shard)
         assert g.counts(out_m) == (31430, 4)                                  # rasterband.rs:180-183
+        # the same pipeline through the sharded entry points (what a C caller without callbacks uses), eager chain
+        n_arr = (C.c_size_t * G)(*lens)
+        red_m2, nir_m2, m_sub, m_add, m_div = (g.alloc(ec.UInt8, lens) for _ in range(5))
+        t_sub, t_add, out2 = (g.alloc(ec.Float64, lens) for _ in range(3))
+        chk(L.ec_sharded_mask_from_nodata(g.handle, ec.UInt16, red.ptrs, n_arr, C.byref(nd), red_m2.ptrs))
+        chk(L.ec_sharded_mask_from_nodata(g.handle, ec.UInt16, nir.ptrs, n_arr, C.byref(nd), nir_m2.ptrs))
+        chk(L.ec_sharded_convert(g.handle, ec.UInt16, red.ptrs, ec.Float32, red_f.ptrs, n_arr))
+        chk(L.ec_sharded_convert(g.handle, ec.UInt16, nir.ptrs, ec.Float32, nir_f.ptrs, n_arr))
+        assert L.ec_sharded_convert(g.handle, ec.Float32, red_f.ptrs, ec.UInt16, red.ptrs, n_arr) == ec._ffi.EC_ERR_NARROWING
+        for op, dst, dm_ in ((ec.SUB, t_sub, m_sub), (ec.ADD, t_add, m_add)):
+            chk(L.ec_sharded_masked_binop(g.handle, op, ec.Float32, nir_f.ptrs, nir_m2.ptrs, ec.Float32, red_f.ptrs, red_m2.ptrs,
+                                          n_arr, dst.ptrs, dm_.ptrs))
+        chk(L.ec_sharded_masked_binop(g.handle, ec.DIV, ec.Float64, t_sub.ptrs, m_sub.ptrs, ec.Float64, t_add.ptrs, m_add.ptrs,
+                                      n_arr, out2.ptrs, m_div.ptrs))
+        assert np.array_equal(g.gather(out2).view(np.uint64), g.gather(out).view(np.uint64))
+        assert np.array_equal(g.gather(m_div), g.gather(out_m)) and g.counts(m_div) == (31430, 4)
+        # and the fused form fanned out by the library: (nir - red) / (nir + 2.5) with a scalar operand, unmasked
+        dt4 = (C.c_uint8 * 4)(ec.Float32, ec.Float32, ec.Float32, 0)
+        PVP = C.POINTER(C.c_void_p)
+        p4 = (PVP * 4)(C.cast(nir_f.ptrs, PVP), C.cast(red_f.ptrs, PVP), C.cast(nir_f.ptrs, PVP), PVP())
+        sc = (ec._ffi.EcValue * 4)()
+        sc[3] = ec.CellValue.new(2.5).to_ec()
+        chk(L.ec_sharded_fused(g.handle, ec.SUB, ec.DIV, ec.ADD, dt4, p4, None, sc, n_arr, out2.ptrs, None))
+        nf, rf = eco.f_convert(nir_h.ravel(), eco.F32), eco.f_convert(red_h.ravel(), eco.F32)
+        exp = eco.f_binop(eco.DIV, eco.f_binop(eco.SUB, nf, rf), eco.f_binop_scalar(eco.ADD, nf, eco.Value.of(eco.F64, 2.5)))
+        assert np.array_equal(g.gather(out2).view(np.uint64), exp.view(np.uint64))
+        for b in (red_m2, nir_m2, m_sub, m_add, m_div, t_sub, t_add, out2):
+            b.free()
         mn, mx = g.min_max(out, out_m)
         assert float(mn.value).hex() == "-0x1.ff8ca5bcc77dcp-4" and float(mx.value).hex() == "0x1.5708125b0ed28p-1"
         # and cell for cell against the oracle's chain on the whole raster

@@ -45,7 +45,7 @@ static void one(const char* name, const void* l, const void* r, double* out, siz
         k_binop_direct<L, R, OP, U, true, true><<<unsigned(tiles), kBlock>>>(static_cast<const L*>(l), static_cast<const R*>(r), out, n, 0u);
     });
     const double bpc = sizeof(L) + sizeof(R) + 8;
-    printf("%-22s U=%d  %.4f ms  %.1f Gcells/s  %.3f of 8 TB/s\n", name, U, ms, n / (ms * 1e-3) / 1e9, bpc * n / (ms * 1e-3) / 1e9 / 8000);
+    printf("%-34s U=%d  %.4f ms  %.1f Gcells/s  %.3f of 8 TB/s\n", name, U, ms, n / (ms * 1e-3) / 1e9, bpc * n / (ms * 1e-3) / 1e9 / 8000);
 }
 
 template <typename L, typename R, int OP>
@@ -76,5 +76,18 @@ int main() {
     sweep<double, float, EC_MUL>("f64 * f32", a, b, out, n);
     sweep<int64_t, double, EC_ADD>("i64 + f64", a, b, out, n);
     sweep<uint8_t, uint8_t, EC_ADD>("u8 + u8", a, b, out, n);
+    // do same-rate streams collide in the memory system?  the second operand and the output moved by odd amounts
+    const size_t offs[] = {0, 256, 4096 + 256, (1 << 16) + 512, (1 << 20) + 4096 + 256, (3 << 20) + 0x1100, (17 << 20) + 0x2300};
+    for (size_t ob : offs)
+        for (size_t oo : {size_t(0), size_t((5 << 20) + 0x900)}) {
+            char name[64];
+            snprintf(name, sizeof name, "u16+u16 b+%zu out+%zu", ob, oo);
+            one<uint16_t, uint16_t, EC_ADD, 2>(name, a, static_cast<char*>(b) + ob, reinterpret_cast<double*>(reinterpret_cast<char*>(out) + oo), n - (32 << 20));
+        }
+    for (size_t ob : offs) {
+        char name[64];
+        snprintf(name, sizeof name, "f32+f32 b+%zu", ob);
+        one<float, float, EC_ADD, 2>(name, a, static_cast<char*>(b) + ob, out, n - (32 << 20));
+    }
     return 0;
 }
