@@ -254,3 +254,55 @@ def test_cell_type_reference_tests():
     assert ec.cell_type_to_string(ec.UInt8) == "UInt8" and ec.cell_type_to_string(ec.Float64) == "Float64"
     with pytest.raises(ec.ParseError):
         ec.cell_type_from_str("UInt57")
+
+
+def test_new_runtime_and_sharding_entry_points_reject_bad_arguments_without_a_device(ec):
+    """Argument and state checks of the round-2 entry points that need no GPU: they fail with a status and a message,
+    never crash, and nothing initialises a device behind the caller's back."""
+    import torch
+    L, E = ec.lib(), ec._ffi
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present: the no-device statuses do not apply")
+    dev = C.c_int32(-1)
+    assert L.ec_set_device(0) == E.EC_ERR_NOT_INITIALIZED and b"ec_init" in L.ec_last_error_string()
+    assert L.ec_get_device(C.byref(dev)) == E.EC_ERR_NOT_INITIALIZED
+    assert L.ec_get_device(None) == E.EC_ERR_ARG
+    assert L.ec_pool_trim(0) == E.EC_ERR_NOT_INITIALIZED
+    assert L.ec_release_stream(None) == E.EC_ERR_NOT_INITIALIZED
+    assert L.ec_free_ordered(None, None, None) == E.EC_OK           # freeing nothing is fine
+    v = C.c_int64(-1)
+    assert L.ec_stat_get(b"devices", C.byref(v)) == E.EC_OK and v.value == 0
+    assert L.ec_stat_get(b"scratch_streams", C.byref(v)) == E.EC_OK and v.value == 0
+    assert L.ec_stat_get(b"pool_allocs", C.byref(v)) == E.EC_OK and v.value == 0
+    assert L.ec_stat_get(b"no such counter", C.byref(v)) == E.EC_ERR_ARG
+    assert L.ec_stat_get(None, C.byref(v)) == E.EC_ERR_ARG
+    for key in (b"pool_keep_mb", b"fused_mixed", b"reduce_shape", b"reduce_bpc"):
+        assert L.ec_tune_set(key, 1) == E.EC_OK
+    assert L.ec_tune_set(b"pool_keep_mb", 32768) == E.EC_OK and L.ec_tune_set(b"fused_mixed", 1) == E.EC_OK
+    assert L.ec_tune_set(b"reduce_shape", 0) == E.EC_OK and L.ec_tune_set(b"reduce_bpc", 0) == E.EC_OK
+    assert L.ec_tune_set(b"nonsense", 1) == E.EC_ERR_ARG
+    # communicators: argument checks come before anything touches RCCL or a device
+    uid, comm = E.EcCommUid(), C.c_void_p()
+    assert L.ec_comm_get_unique_id(None) == E.EC_ERR_ARG
+    assert L.ec_comm_init_rank(None, 1, 0, C.byref(comm)) == E.EC_ERR_ARG
+    assert L.ec_comm_init_rank(C.byref(uid), 2, 2, C.byref(comm)) == E.EC_ERR_ARG
+    assert L.ec_comm_init_rank(C.byref(uid), 1, 0, C.byref(comm)) == E.EC_ERR_NOT_INITIALIZED
+    assert L.ec_comm_init_all(None, 1, None) == E.EC_ERR_ARG
+    assert L.ec_comm_init_all((C.c_int32 * 2)(3, 3), 2, (C.c_void_p * 2)()) == E.EC_ERR_ARG and b"listed twice" in L.ec_last_error_string()
+    assert L.ec_comm_destroy(None) == E.EC_OK
+    assert L.ec_allreduce_min_max_keys(None, None, None) == E.EC_ERR_NOT_INITIALIZED
+    # shard groups
+    g = C.c_void_p()
+    assert L.ec_shard_group_create(None, 1, 0, C.byref(g)) == E.EC_ERR_ARG
+    assert L.ec_shard_group_create((C.c_int32 * 1)(0), 0, 0, C.byref(g)) == E.EC_ERR_ARG
+    assert L.ec_shard_group_create((C.c_int32 * 2)(1, 1), 2, 0, C.byref(g)) == E.EC_ERR_ARG          # RCCL needs distinct devices
+    assert L.ec_shard_group_create((C.c_int32 * 1)(0), 1, 1, C.byref(g)) == E.EC_ERR_HIP and not g.value  # no device here
+    assert L.ec_shard_group_destroy(None) == E.EC_OK and L.ec_shard_group_size(None) == 0
+    n1, p1 = (C.c_size_t * 1)(4), (C.c_void_p * 1)()
+    for st in (L.ec_shard_group_sync(None), L.ec_sharded_alloc(None, n1, p1), L.ec_sharded_free(None, p1),
+               L.ec_sharded_binop(None, 0, 0, p1, 0, p1, n1, p1), L.ec_sharded_convert(None, 0, p1, 1, p1, n1),
+               L.ec_sharded_counts(None, p1, n1, C.byref(C.c_uint64()), C.byref(C.c_uint64())),
+               L.ec_shard_group_shard(None, 0, None, None)):
+        assert st == E.EC_ERR_ARG and b"null shard group" in L.ec_last_error_string()
+    # still nothing initialised
+    assert L.ec_stat_get(b"devices", C.byref(v)) == E.EC_OK and v.value == 0
