@@ -128,6 +128,62 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
 }
 
 
+// The two operand configurations almost every call has — every operand its own buffer, or the NDVI aliasing
+// `(x o1 y) o2 (x o3 y)` — with no scalar operand, on a full tile: everything launch-uniform in the general tile
+// (which slots load, which alias which, which are scalars, the per-pair bounds check) is known, so the tile is
+// straight-line code like k_binop_direct's.  The general tile costs the NDVI kernel ≈3 % (85 selects and several
+// hundred scalar instructions on its hot path); slot types may differ (ec_fused_mixed.hpp).
+template <typename TX, typename TY, typename TZ, typename TW, int O1, int O2, int O3, int U, bool NDVI>
+__device__ __forceinline__ void fused_fast_tile(const vec<TX, 2>* __restrict__ px, const vec<TY, 2>* __restrict__ py,
+                                                const vec<TZ, 2>* __restrict__ pz, const vec<TW, 2>* __restrict__ pw,
+                                                D2* __restrict__ op, size_t base) {
+    constexpr bool has_w = O3 != kOpNone;
+    constexpr bool kSmall = is_small_int<TX>::value && is_small_int<TY>::value && is_small_int<TZ>::value &&
+                            (!has_w || is_small_int<TW>::value) && is_ndvi_shape<O1, O2, O3>::value;
+    vec<TX, 2> x[U];
+    vec<TY, 2> y[U];
+    vec<TZ, 2> z[U] = {};
+    vec<TW, 2> w[U] = {};
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const size_t pr = base + size_t(j) * kBlock;
+        x[j] = nt_load(px + pr);
+        y[j] = nt_load(py + pr);
+        if constexpr (!NDVI) {
+            z[j] = nt_load(pz + pr);
+            if constexpr (has_w) w[j] = nt_load(pw + pr);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const D2 vx{to_f64(x[j].x), to_f64(x[j].y)}, vy{to_f64(y[j].x), to_f64(y[j].y)};
+        D2 vz = vx, vw = vy;  // NDVI: z is x, w is y
+        if constexpr (!NDVI) {
+            vz = D2{to_f64(z[j].x), to_f64(z[j].y)};
+            if constexpr (has_w) vw = D2{to_f64(w[j].x), to_f64(w[j].y)};
+        }
+        D2 o;
+        if constexpr (kSmall) {
+            o.x = ndvi_shape_small_int<O1, O3>(vx.x, vy.x, vz.x, vw.x);
+            o.y = ndvi_shape_small_int<O1, O3>(vx.y, vy.y, vz.y, vw.y);
+        } else {
+            o.x = fused_cell_t<O1, O2, O3>(vx.x, vy.x, vz.x, vw.x);
+            o.y = fused_cell_t<O1, O2, O3>(vx.y, vy.y, vz.y, vw.y);
+        }
+        nt_store(o, op + base + size_t(j) * kBlock);
+    }
+}
+
+// launch-uniform: which straight-line tile, if any, serves this call (0 none, 1 all operands distinct, 2 NDVI aliasing)
+template <bool HAS_W>
+__device__ __forceinline__ int fused_fast_config(const FusedArgs& fa) {
+    if (fa.is_sc[0] | fa.is_sc[1] | fa.is_sc[2] | (HAS_W ? fa.is_sc[3] : 0)) return 0;
+    if (fa.alias[1] != 1) return 0;
+    if (fa.alias[2] == 2 && (!HAS_W || fa.alias[3] == 3)) return 1;
+    if (HAS_W && fa.alias[2] == 0 && fa.alias[3] == 1) return 2;
+    return 0;
+}
+
 // One workgroup per tile of kBlock*fused_u(sizeof T) pairs, two-front order, as k_binop_direct.  All buffer
 // operands have cell type T.
 template <typename T, int O1, int O2, int O3>
@@ -151,6 +207,12 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
     const bool full = tile * TILE + TILE <= npairs;  // every pair of the tile exists: no per-pair guards
     constexpr bool kSmallShape = is_small_int<T>::value && is_ndvi_shape<O1, O2, O3>::value;
     const bool small_ints = kSmallShape && !(fa.is_sc[0] | fa.is_sc[1] | fa.is_sc[2] | (has_w ? fa.is_sc[3] : 0));  // no scalar operand
+    const int fast = full ? fused_fast_config<has_w>(fa) : 0;
+    if (fast == 1) {
+        fused_fast_tile<T, T, T, T, O1, O2, O3, kFusedU, false>(px, py, pz, pw, op, base);
+    } else if (has_w && fast == 2) {
+        fused_fast_tile<T, T, T, T, O1, O2, O3, kFusedU, true>(px, py, pz, pw, op, base);
+    } else {
     T2 x[kFusedU] = {}, y[kFusedU] = {}, z[kFusedU] = {}, w[kFusedU] = {};
 #pragma unroll
     for (int j = 0; j < kFusedU; ++j) {
@@ -186,6 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
             nt_store(o, op + pr);
         }
     }
+    }  // general tile
     if (blockIdx.x == 0 && threadIdx.x < 2) {  // the peeled head cell (lane 0) and the odd tail cell (lane 1)
         const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;
         const size_t i = threadIdx.x == 0 ? 0 : n - 1;

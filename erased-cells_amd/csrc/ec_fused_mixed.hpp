@@ -73,6 +73,13 @@ __global__ __launch_bounds__(kBlock) void k_fused_mixed(FusedArgs fa, double* __
     const bool full = tile * TILE + TILE <= npairs;
     constexpr bool kSmallShape = is_small_int<A>::value && is_small_int<B>::value && is_ndvi_shape<O1, O2, O3>::value;
     const bool small_ints = kSmallShape && !(fa.is_sc[0] | fa.is_sc[1] | fa.is_sc[2] | (has_w ? fa.is_sc[3] : 0));
+    constexpr bool kNdviTypes = std::is_same<TZ, TX>::value && std::is_same<TW, TY>::value;
+    const int fast = full ? fused_fast_config<has_w>(fa) : 0;
+    if (fast == 1) {
+        fused_fast_tile<TX, TY, TZ, TW, O1, O2, O3, kFusedU, false>(px, py, pz, pw, op, base);
+    } else if (has_w && kNdviTypes && fast == 2) {
+        if constexpr (has_w && kNdviTypes) fused_fast_tile<TX, TY, TZ, TW, O1, O2, O3, kFusedU, true>(px, py, pz, pw, op, base);
+    } else {
     X2 x[kFusedU] = {};
     Y2 y[kFusedU] = {};
     Z2 z[kFusedU] = {};
@@ -119,6 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_mixed(FusedArgs fa, double* __
             nt_store(o, op + pr);
         }
     }
+    }  // general tile
     if (blockIdx.x == 0 && threadIdx.x < 2) {  // the peeled head cell (lane 0) and the odd tail cell (lane 1)
         const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;
         const size_t i = threadIdx.x == 0 ? 0 : n - 1;
