@@ -131,8 +131,11 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
 // The two operand configurations almost every call has — every operand its own buffer, or the NDVI aliasing
 // `(x o1 y) o2 (x o3 y)` — with no scalar operand, on a full tile: everything launch-uniform in the general tile
 // (which slots load, which alias which, which are scalars, the per-pair bounds check) is known, so the tile is
-// straight-line code like k_binop_direct's.  The general tile costs the NDVI kernel ≈3 % (85 selects and several
-// hundred scalar instructions on its hot path); slot types may differ (ec_fused_mixed.hpp).
+// straight-line code like k_binop_direct's (the general tile of the NDVI kernel carries 85 selects and several hundred
+// scalar instructions).  MEASURED AND NOT USED: on one box, same run (profiles/r02/tune_fused_fast_tiles.log) the
+// straight-line tiles gave NDVI u16 0.779 against 0.774 for the general tile, but NDVI u16 + f32 0.762 against 0.772,
+// config 3 0.764 against 0.778 and (a+b)*c on f32 0.782 against 0.797 — these kernels wait on HBM, not on their
+// instruction count.  The code stays behind EC_FUSED_FAST_TILES (off) so the comparison can be repeated.
 template <typename TX, typename TY, typename TZ, typename TW, int O1, int O2, int O3, int U, bool NDVI>
 __device__ __forceinline__ void fused_fast_tile(const vec<TX, 2>* __restrict__ px, const vec<TY, 2>* __restrict__ py,
                                                 const vec<TZ, 2>* __restrict__ pz, const vec<TW, 2>* __restrict__ pw,
@@ -177,6 +180,9 @@ __device__ __forceinline__ void fused_fast_tile(const vec<TX, 2>* __restrict__ p
 // launch-uniform: which straight-line tile, if any, serves this call (0 none, 1 all operands distinct, 2 NDVI aliasing)
 template <bool HAS_W>
 __device__ __forceinline__ int fused_fast_config(const FusedArgs& fa) {
+#ifndef EC_FUSED_FAST_TILES  // OFF in the library: measured slower, see above (build-time A/B switch, tools/tune_fused2.hip)
+    return 0;
+#endif
     if (fa.is_sc[0] | fa.is_sc[1] | fa.is_sc[2] | (HAS_W ? fa.is_sc[3] : 0)) return 0;
     if (fa.alias[1] != 1) return 0;
     if (fa.alias[2] == 2 && (!HAS_W || fa.alias[3] == 3)) return 1;

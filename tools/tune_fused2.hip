@@ -2,6 +2,7 @@
 //   config 3   (a + b) * c on f32 with three masks (24 B/cell)      k_fused_same<float, Add, Mul, none>
 //   NDVI u16   (x - y) / (x + y), aliased operands (12 B/cell)       k_fused_same<uint16_t, Sub, Div, Add>
 //   NDVI mixed u16 + f32 bands in one pass (14 B/cell)                k_fused_mixed<uint16_t, float, ABAB, Sub, Div, Add>
+//   (add -DEC_FUSED_FAST_TILES for the straight-line tiles of ec_fused_kernels.hpp; without -DEC_FUSED_U the per-type depth)
 //   for U in 2 4 8; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -ffp-contract=off -DEC_FUSED_U=$U \
 //       -Iinclude -Ierased-cells_amd/csrc tools/tune_fused2.hip -o tools/tune_fused2_u$U; done
 #include <hip/hip_runtime.h>
@@ -14,6 +15,11 @@
 #include "ec_fused_mixed.hpp"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 using namespace ecd;
+#ifdef EC_FUSED_FAST_TILES
+#define VARIANT " fast tiles "
+#else
+#define VARIANT " general tile"
+#endif
 
 __global__ void k_fill(uint16_t* a, float* b, float* c, float* d, uint8_t* m0, uint8_t* m1, uint8_t* m2, size_t n) {
     size_t stride = size_t(gridDim.x) * blockDim.x;
@@ -39,8 +45,12 @@ int main() {
     CK(hipMalloc(&out, n * 8));
     k_fill<<<2048, 256>>>(a, b, c, d, m0, m1, m2, n);
     CK(hipDeviceSynchronize());
-    constexpr int kFusedU = fused_u(1);  // the forced depth of this build
-    const unsigned grid = unsigned((n / 2 + 256 * size_t(kFusedU) - 1) / (256 * size_t(kFusedU)));
+    #ifdef EC_FUSED_U
+    constexpr int kFusedU = EC_FUSED_U;  // the forced depth of this build
+#else
+    constexpr int kFusedU = 0;  // per-kernel depth (fused_u): grids are computed per kernel below
+#endif
+    auto grid_of = [&](size_t cell_bytes) { const size_t u = kFusedU ? size_t(kFusedU) : size_t(fused_u(cell_bytes)); return unsigned((n / 2 + 256 * u - 1) / (256 * u)); };
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&](const char* name, double bpc, auto f) {
@@ -54,7 +64,7 @@ int main() {
             ms.push_back(t / 60);
         }
         std::sort(ms.begin(), ms.end());
-        printf("U=%d  %-34s %.4f ms  %.1f Gcells/s  %.3f of 8 TB/s\n", kFusedU, name, ms[3], n / (ms[3] * 1e-3) / 1e9, bpc * n / (ms[3] * 1e-3) / 1e9 / 8000);
+        printf("U=%d%s  %-34s %.4f ms  %.1f Gcells/s  %.3f of 8 TB/s\n", kFusedU, VARIANT, name, ms[3], n / (ms[3] * 1e-3) / 1e9, bpc * n / (ms[3] * 1e-3) / 1e9 / 8000);
     };
     FusedArgs c3{};  // (c + d) * b with masks
     c3.p[0] = c; c3.p[1] = d; c3.p[2] = b; c3.p[3] = b;
@@ -77,10 +87,10 @@ int main() {
     mx.alias[0] = 0; mx.alias[1] = 1; mx.alias[2] = 0; mx.alias[3] = 1;
     mx.o1 = EC_SUB; mx.o2 = EC_DIV; mx.o3 = EC_ADD;
     for (int rep = 0; rep < 2; ++rep) {
-        run("config 3 (a+b)*c f32 + 3 masks", 24, [&] { k_fused_same<float, EC_ADD, EC_MUL, kOpNone><<<grid, 256>>>(c3, out, om, n); });
-        run("(a+b)*c f32, no masks", 20, [&] { k_fused_same<float, EC_ADD, EC_MUL, kOpNone><<<grid, 256>>>(c3u, out, nullptr, n); });
-        run("NDVI u16", 12, [&] { k_fused_same<uint16_t, EC_SUB, EC_DIV, EC_ADD><<<grid, 256>>>(nd, out, nullptr, n); });
-        run("NDVI u16 + f32, one pass", 14, [&] { k_fused_mixed<uint16_t, float, kPatABAB, EC_SUB, EC_DIV, EC_ADD><<<grid, 256>>>(mx, out, nullptr, n); });
+        run("config 3 (a+b)*c f32 + 3 masks", 24, [&] { k_fused_same<float, EC_ADD, EC_MUL, kOpNone><<<grid_of(4), 256>>>(c3, out, om, n); });
+        run("(a+b)*c f32, no masks", 20, [&] { k_fused_same<float, EC_ADD, EC_MUL, kOpNone><<<grid_of(4), 256>>>(c3u, out, nullptr, n); });
+        run("NDVI u16", 12, [&] { k_fused_same<uint16_t, EC_SUB, EC_DIV, EC_ADD><<<grid_of(2), 256>>>(nd, out, nullptr, n); });
+        run("NDVI u16 + f32, one pass", 14, [&] { k_fused_mixed<uint16_t, float, kPatABAB, EC_SUB, EC_DIV, EC_ADD><<<grid_of(2), 256>>>(mx, out, nullptr, n); });
     }
     return 0;
 }
