@@ -371,6 +371,12 @@ def main():
     # (profiles/r01/warmup_sensitivity.txt).  Untimed ramp launches run first until both --ramp launches
     # and --ramp-ms of wall time have passed (a 1/8 shard's step is only ≈60 µs); their number is
     # disclosed as config.clock_ramp_steps.  Then the W warm-up steps the caller asked for.
+    # The collector is emptied BEFORE the ramp (a collection between warm-up and timing would idle the GPU for tens of
+    # milliseconds and undo the ramp) and stays off until the timed region has ended: a collector pause inside a 1 ms
+    # timed region (K steps of a 1/8 shard) would be a tenth of it.
+    import gc
+    gc.collect()
+    gc.disable()
     ramp = 0
     t_ramp = time.perf_counter()
     while args.ramp > 0 and (ramp < args.ramp or (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms):
@@ -397,9 +403,6 @@ def main():
         ec.set_stream(stream)
         graph.replay()  # first replay uploads the graph
         torch.cuda.synchronize()
-    import gc
-    gc.collect()
-    gc.disable()  # a collector pause inside a 1 ms timed region (K steps of a 1/8 shard) would be a tenth of it
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
