@@ -377,6 +377,9 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    if use_dist:
+        barrier()  # ranks enter the ramp together, so they reach the timing barrier within microseconds of each other:
+                   # a rank that waited there for long would start its timed steps on an idle, down-clocked GPU
     ramp = 0
     t_ramp = time.perf_counter()
     while args.ramp > 0 and (ramp < args.ramp or (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms):
