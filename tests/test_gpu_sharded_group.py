@@ -402,3 +402,24 @@ def test_config5_ndvi_in_one_process_over_a_shard_group(ec, golden_dir, G):
             g.foreach(lambda i, d, s: 1 // 0)                                 # a failing shard function surfaces here
         for b in (red, nir, red_f, nir_f, red_m, nir_m, out_m, out):
             b.free()
+
+
+def _build_example(tmp_path, name):
+    exe = str(tmp_path / name)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", name + ".c"), "-L" + LIBDIR, "-lerased_cells_hip",
+                        "-Wl,-rpath," + LIBDIR, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_lifecycle_example_is_plain_c99_and_links(tmp_path):
+    _build_example(tmp_path, "lifecycle")
+
+
+@pytest.mark.gpu
+def test_runtime_lifecycle_init_shutdown_init_from_plain_c(tmp_path):
+    """ec_init -> work -> ec_shutdown (pool destroyed, scratch freed) -> ec_init again, three times over, in one process."""
+    r = subprocess.run([_build_example(tmp_path, "lifecycle")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.split() == ["round", "0", "ok", "round", "1", "ok", "round", "2", "ok"]
