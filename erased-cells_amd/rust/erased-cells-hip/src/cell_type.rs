@@ -1,9 +1,11 @@
-//! `CellType` (src/ctype.rs:11-180 of the reference): the ten cell encodings.  `self as u8` IS the ABI dtype
+//! `CellType` (src/ctype.rs:11-180 of the reference) and `CellEncoding` (src/encoding.rs:9-40): the ten cell encodings
+//! and the primitives that carry them.  `self as u8` IS the ABI dtype
 //! code; the lattice (`union`, `can_fit_into`, limits) is answered by the library's host-side table, the same
 //! one its kernel dispatch uses.
 use crate::error::Error;
 use crate::ffi::*;
 use crate::CellValue;
+use num_traits::{One, Zero};
 use std::fmt::{Debug, Display, Formatter};
 use std::str::FromStr;
 
@@ -103,3 +105,48 @@ impl CellType {
         CellValue::from_ffi(&v)
     }
 }
+
+/// Trait for marking Rust primitives as having a corresponding [`CellType`]: implemented for exactly the ten
+/// primitives a cell can hold (`u8` … `f64`); `isize`, `bool`, `u128` … are not cell encodings.
+pub trait CellEncoding: Copy + Debug + Default + Zero + One + PartialEq {
+    /// Returns the [`CellType`] covering `Self`.
+    fn cell_type() -> CellType;
+    /// Converts `self` into a [`CellValue`].
+    fn into_cell_value(self) -> CellValue;
+    /// Convert dynamic type to static type when logically known: `Some` only when `T` is exactly `Self` (equal cell
+    /// types mean the same primitive, so the value is copied bit for bit), `None` for every other pair — there is
+    /// no numeric conversion here, that is `CellValue::convert`'s job.
+    fn static_cast<T: CellEncoding + Sized>(value: T) -> Option<Self> {
+        (Self::cell_type() == T::cell_type()).then(|| {
+            debug_assert_eq!(std::mem::size_of::<T>(), std::mem::size_of::<Self>());
+            let mut same = Self::default();
+            unsafe {
+                std::ptr::copy_nonoverlapping(&value as *const T as *const u8, &mut same as *mut Self as *mut u8, std::mem::size_of::<Self>())
+            };
+            same
+        })
+    }
+}
+
+macro_rules! cell_encoding_of {
+    ($prim:ty => $ct:ident) => {
+        impl CellEncoding for $prim {
+            fn cell_type() -> CellType {
+                CellType::$ct
+            }
+            fn into_cell_value(self) -> CellValue {
+                CellValue::$ct(self)
+            }
+        }
+    };
+}
+cell_encoding_of!(u8 => UInt8);
+cell_encoding_of!(u16 => UInt16);
+cell_encoding_of!(u32 => UInt32);
+cell_encoding_of!(u64 => UInt64);
+cell_encoding_of!(i8 => Int8);
+cell_encoding_of!(i16 => Int16);
+cell_encoding_of!(i32 => Int32);
+cell_encoding_of!(i64 => Int64);
+cell_encoding_of!(f32 => Float32);
+cell_encoding_of!(f64 => Float64);

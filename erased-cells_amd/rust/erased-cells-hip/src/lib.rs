@@ -16,7 +16,6 @@
 //! tested, exists in C++ (`host/erased_cells.hpp`) and Python (`python/erased_cells_hip`); see INTEGRATION.md.
 pub mod ffi;
 
-mod cell_encoding;
 mod cell_type;
 mod cell_value;
 mod device;
@@ -29,10 +28,9 @@ pub mod fused;
 #[cfg(feature = "masked")]
 mod masked;
 #[cfg(feature = "masked")]
-mod nodata;
+mod sentinel;
 pub mod sharded;
 
-pub use cell_encoding::*;
 pub use cell_type::*;
 pub use cell_value::*;
 pub use device::{init, set_stream, stream};
@@ -42,7 +40,7 @@ pub use device_mask::*;
 #[cfg(feature = "masked")]
 pub use masked::*;
 #[cfg(feature = "masked")]
-pub use nodata::*;
+pub use sentinel::*;
 use std::fmt::{Debug, Formatter};
 
 /// `with_ct` is a callback style macro used to construct various implementations covering all [`CellType`]s.

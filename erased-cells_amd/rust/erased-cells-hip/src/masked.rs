@@ -1,31 +1,35 @@
 //! `MaskedCellBuffer` (src/masked/masked_buffer.rs of the reference): a [`CellBuffer`] with a companion [`Mask`],
-//! both device-resident.  The value op over ALL cells and the AND of the masks run as one launch.
+//! both device-resident.  Arithmetic computes the value op over ALL cells (masked-out ones included, as the reference
+//! does — they take part in the derived `PartialEq`) and ANDs the masks, in one launch; `min_max`, `counts` and
+//! `to_vec_with_nodata` are the places where the mask decides.
 use crate::device::stream;
 use crate::error::{check, must};
 use crate::ffi::*;
 use crate::{BufferOps, CellBuffer, CellEncoding, CellType, CellValue, Mask, NoData};
 use std::fmt::{Debug, Formatter};
 
-/// A [`CellBuffer`] with a companion [`Mask`].
-///
-/// The `Mask` tracks which cells are valid across operations, and which should be treated as "no-data" values.
+/// A [`CellBuffer`] with a companion [`Mask`] of the same length: `true` marks a valid cell, `false` a no-data cell.
 #[derive(Clone, PartialEq, PartialOrd)]
 pub struct MaskedCellBuffer(CellBuffer, Mask);
 
 impl MaskedCellBuffer {
-    /// Create a new combined [`CellBuffer`] and [`Mask`].
+    /// Pair a buffer with its mask.
     ///
     /// # Panics
-    /// Will panics if `buffer` and `mask` are not the same length.
+    /// When the two lengths differ.
     pub fn new(buffer: CellBuffer, mask: Mask) -> Self {
         assert_eq!(buffer.len(), mask.len(), "Mask and buffer must have the same length.");
         Self(buffer, mask)
     }
 
-    /// Constructs a `MaskedCellBuffer` from a `Vec<CellEncoding>`, specifying a `NoData<T>` value.
-    ///
-    /// Mask value will be `false` when associated cell matches `nodata` (one kernel over the uploaded cells;
-    /// the reference walks the cells with `IsNodata::is`, which stays available for single values).
+    /// `buffer` with every cell valid (what `from_vec`, `fill`, `with_defaults`, `fill_via` and `From<CellBuffer>` build).
+    fn all_valid(buffer: CellBuffer) -> Self {
+        let mask = Mask::fill(buffer.len(), true);
+        Self(buffer, mask)
+    }
+
+    /// Upload `data` and derive the mask from a sentinel: `false` exactly where a cell equals `nodata` under the total
+    /// order (one kernel over the uploaded cells; `IsNodata::is` does the same test for a single value on the host).
     pub fn from_vec_with_nodata<T: CellEncoding>(data: Vec<T>, nodata: NoData<T>) -> Self {
         let buf = CellBuffer::from_vec(data);
         let mask = Mask::uninit(buf.len());
@@ -62,37 +66,30 @@ impl MaskedCellBuffer {
         &mut self.1
     }
 
-    /// Get a buffer value at position `index` with mask evaluated.
-    ///
-    /// Returns `Some(CellValue)` if mask at `index` is `true`, `None` otherwise.
+    /// The cell at `index` if it is valid, `None` if it is masked out (two one-cell downloads).
     pub fn get_masked(&self, index: usize) -> Option<CellValue> {
-        if self.mask().get(index) {
-            Some(self.buffer().get(index))
-        } else {
-            None
-        }
+        self.1.get(index).then(|| self.0.get(index))
     }
 
-    /// Get the cell value and mask value at position `index`.
+    /// The cell at `index` together with its validity flag.
     pub fn get_with_mask(&self, index: usize) -> (CellValue, bool) {
-        (self.buffer().get(index), self.mask().get(index))
+        (self.0.get(index), self.1.get(index))
     }
 
-    /// Set the `value` and `mask` at position `index`.
-    ///
-    /// Returns `Err(NarrowingError)` if `value` cannot be converted to `self.cell_type()` without data loss.
+    /// Overwrite cell and validity flag at `index`; `Err(NarrowingError)` (nothing written) when `value`'s cell type
+    /// does not fit the buffer's.
     pub fn put_with_mask(&mut self, index: usize, value: CellValue, mask: bool) -> crate::error::Result<()> {
-        self.put(index, value)?;
-        self.mask_mut().put(index, mask);
+        self.0.put(index, value)?;
+        self.1.put(index, mask);
         Ok(())
     }
 
-    /// Returns a tuple of representing counts of `(data, nodata)`.
+    /// `(data, nodata)`: the numbers of valid and of masked-out cells (a device reduction).
     pub fn counts(&self) -> (usize, usize) {
-        self.mask().counts()
+        self.1.counts()
     }
 
-    /// Convert `self` into a `Vec<T>`, replacing values where the mask is `0` to `no_data.value()`
+    /// Download as `Vec<T>` with every masked-out cell replaced by `no_data.value()` (`NoData::None`: the cells as they are)
     pub fn to_vec_with_nodata<T: CellEncoding>(self, no_data: NoData<T>) -> crate::error::Result<Vec<T>> {
         let Self(buf, mask) = self;
         let conv = buf.convert(T::cell_type())?;
@@ -125,22 +122,17 @@ impl MaskedCellBuffer {
 }
 
 impl BufferOps for MaskedCellBuffer {
+    // the four constructors: the cells as CellBuffer builds them, every one valid
     fn from_vec<T: CellEncoding>(data: Vec<T>) -> Self {
-        let buffer = CellBuffer::from_vec(data);
-        let mask = Mask::fill(buffer.len(), true);
-        Self::new(buffer, mask)
+        Self::all_valid(CellBuffer::from_vec(data))
     }
 
     fn with_defaults(len: usize, ct: CellType) -> Self {
-        let buffer = CellBuffer::with_defaults(len, ct);
-        let mask = Mask::fill(len, true);
-        Self::new(buffer, mask)
+        Self::all_valid(CellBuffer::with_defaults(len, ct))
     }
 
     fn fill(len: usize, value: CellValue) -> Self {
-        let buffer = CellBuffer::fill(len, value);
-        let mask = Mask::fill(len, true);
-        Self::new(buffer, mask)
+        Self::all_valid(CellBuffer::fill(len, value))
     }
 
     fn fill_via<T, F>(len: usize, f: F) -> Self
@@ -148,33 +140,32 @@ impl BufferOps for MaskedCellBuffer {
         T: CellEncoding,
         F: Fn(usize) -> T,
     {
-        let buffer = CellBuffer::fill_via(len, f);
-        let mask = Mask::fill(len, true);
-        Self::new(buffer, mask)
+        Self::all_valid(CellBuffer::fill_via(len, f))
     }
 
+    // the accessors look at the cells only
     fn len(&self) -> usize {
-        self.buffer().len()
+        self.0.len
     }
 
     fn cell_type(&self) -> CellType {
-        self.buffer().cell_type()
+        self.0.ct
     }
 
     fn get(&self, index: usize) -> CellValue {
-        self.buffer().get(index)
+        self.0.get(index)
     }
 
     fn put(&mut self, idx: usize, value: CellValue) -> crate::error::Result<()> {
-        self.buffer_mut().put(idx, value)
+        self.0.put(idx, value)
     }
 
+    /// The cells widened to `cell_type` (refused up front if that would narrow), the mask carried over.
     fn convert(&self, cell_type: CellType) -> crate::error::Result<Self>
     where
         Self: Sized,
     {
-        let converted = self.buffer().convert(cell_type)?;
-        Ok(Self::new(converted, self.mask().to_owned()))
+        self.0.convert(cell_type).map(|cells| Self(cells, self.1.clone()))
     }
 
     /// `min_max` restricted to the cells whose mask is `true` (all masked -> the inverted sentinels).
@@ -215,11 +206,10 @@ impl<'a> From<&'a MaskedCellBuffer> for (&'a CellBuffer, &'a Mask) {
     }
 }
 
-/// Converts a [`CellBuffer`] into a [`MaskedCellBuffer`] with an all-true mask.
+/// A plain buffer becomes a masked one with every cell valid.
 impl From<CellBuffer> for MaskedCellBuffer {
     fn from(value: CellBuffer) -> Self {
-        let len = value.len();
-        Self::new(value, Mask::fill(len, true))
+        Self::all_valid(value)
     }
 }
 
