@@ -256,7 +256,9 @@ def main():
     args.gpus = world  # under a launcher the launcher's world size is authoritative
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
-    dev = 0 if args.single_device else local_rank
+    ndev = max(1, torch.cuda.device_count())
+    # one rank per GPU; when a launcher masks the devices per rank (each rank sees only its own as device 0) use that one
+    dev = 0 if args.single_device else (local_rank if local_rank < ndev else local_rank % ndev)
     torch.cuda.set_device(dev)
     use_dist = world > 1 or os.environ.get("EC_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal of the RCCL path
     if use_dist:
