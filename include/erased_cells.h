@@ -116,7 +116,8 @@ ec_status ec_device_info(int32_t *n_cu, uint64_t *hbm_bytes, char *name, size_t 
 
 ec_status ec_alloc(void **dptr, size_t bytes);
 ec_status ec_free(void *dptr);
-/* Stream-ordered allocation from the device's memory pool (hipMallocAsync / hipFreeAsync): what the host
+/* Stream-ordered allocation from the library's own pool on the current device (hipMallocFromPoolAsync /
+ * hipFreeAsync; the device's default pool is never touched): what the host
  * mirrors use for operator results, which the reference allocates per call (`collect()`,
  * src/buffer.rs:327).  A block may be used by work enqueued on `stream` after the call, and freed
  * blocks are recycled without synchronising the device. */
