@@ -25,6 +25,18 @@ static_assert(kMaxReduceBlocks <= kFinalizeMaxParts, "the finalize kernels read 
 
 static ec_status ensure_init() { return ensure_ready(); }
 
+// Where the last kernel of a synchronous-result call writes its 1-2 result words: the stream's pinned host words as the
+// device sees them (zero-copy: the result is on the host when the stream has drained), or device scratch when the
+// mapping is unavailable.  fetch_result waits for the stream (and copies first in the fallback case).
+static int64_t* result_words(const Scratch& sc) { return sc.host_dev ? sc.host_dev : sc.dev_result(); }
+static ec_status fetch_result(const Scratch& sc, int words, hipStream_t s) {
+    if (!sc.host_dev) {
+        ec_status st = check_hip(hipMemcpyAsync(sc.host, sc.dev_result(), words * sizeof(int64_t), hipMemcpyDeviceToHost, s), "hipMemcpyAsync");
+        if (st != EC_OK) return st;
+    }
+    return check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+}
+
 // Workgroups of `kernel` (BLOCK threads, no dynamic LDS) that fit on one CU at a time, at most `want`.
 template <typename K>
 static int resident_per_cu(K kernel, int block, int want) {
@@ -391,11 +403,9 @@ extern "C" ec_status ec_min_max(ec_dtype t, const void* p, const uint8_t* mask_o
     ec_status st = get_scratch(S(stream), &sc);
     if (st != EC_OK) return st;
     std::lock_guard<std::mutex> turn(*sc.mu);  // the pinned result words are per stream: host threads sharing it take turns
-    st = dispatch_min_max(t, p, mask_or_null, n, sc.dev_result(), S(stream));
+    st = dispatch_min_max(t, p, mask_or_null, n, result_words(sc), S(stream));  // the last kernel writes the pinned words
     if (st != EC_OK) return st;
-    st = check_hip(hipMemcpyAsync(sc.host, sc.dev_result(), 2 * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync");
-    if (st != EC_OK) return st;
-    st = check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+    st = fetch_result(sc, 2, S(stream));
     if (st != EC_OK) return st;
     return ec_min_max_decode(t, sc.host, mn, mx);
 }
@@ -434,12 +444,10 @@ extern "C" ec_status ec_first_difference(ec_dtype t, const void* l, const void* 
     }
     if (st != EC_OK) return st;
     k_first_diff_finalize<<<1, kFinalizeBlock, 0, S(stream)>>>(reinterpret_cast<const uint64_t*>(sc.dev), static_cast<int>(grid),
-                                                       reinterpret_cast<uint64_t*>(sc.dev_result()));
+                                                       reinterpret_cast<uint64_t*>(result_words(sc)));
     st = check_launch("first_diff(finalize)");
     if (st != EC_OK) return st;
-    st = check_hip(hipMemcpyAsync(sc.host, sc.dev_result(), sizeof(uint64_t), hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync");
-    if (st != EC_OK) return st;
-    st = check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+    st = fetch_result(sc, 1, S(stream));
     if (st != EC_OK) return st;
     const uint64_t first = static_cast<uint64_t>(sc.host[0]);
     *index = first == ~0ull ? n : first;
@@ -581,11 +589,9 @@ extern "C" ec_status ec_mask_counts(const uint8_t* m, size_t n, uint64_t* n_true
     ec_status st = get_scratch(S(stream), &sc);
     if (st != EC_OK) return st;
     std::lock_guard<std::mutex> turn(*sc.mu);
-    st = ec_mask_counts_device(m, n, reinterpret_cast<uint64_t*>(sc.dev_result()), stream);
+    st = ec_mask_counts_device(m, n, reinterpret_cast<uint64_t*>(result_words(sc)), stream);
     if (st != EC_OK) return st;
-    st = check_hip(hipMemcpyAsync(sc.host, sc.dev_result(), 2 * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync");
-    if (st != EC_OK) return st;
-    st = check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");
+    st = fetch_result(sc, 2, S(stream));
     if (st != EC_OK) return st;
     *n_true = static_cast<uint64_t>(sc.host[0]);
     *n_false = static_cast<uint64_t>(sc.host[1]);

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -147,6 +148,10 @@ ec_status get_scratch(hipStream_t s, Scratch* out) {
         st = check_hip(hipHostMalloc(reinterpret_cast<void**>(&e.sc.host), 4 * sizeof(int64_t), hipHostMallocDefault),
                        "hipHostMalloc(scratch)");
         if (st != EC_OK) { (void)hipFree(e.sc.dev); return st; }
+        void* as_device = nullptr;
+        static const bool no_zero_copy = std::getenv("EC_NO_ZERO_COPY_RESULTS") != nullptr;  // A/B switch
+        if (!no_zero_copy && hipHostGetDevicePointer(&as_device, e.sc.host, 0) == hipSuccess && as_device) e.sc.host_dev = static_cast<int64_t*>(as_device);
+        else (void)hipGetLastError();  // host_dev stays null: results go through dev_result() and a copy
         e.sc.mu = new std::mutex;
         it = table.emplace(s, e).first;
     }

@@ -107,7 +107,9 @@ inline unsigned grid_capped(size_t blocks, int bpc) {
 // one stream therefore take turns instead of racing on the four pinned words.
 struct Scratch {
     int64_t* dev = nullptr;    // 2*kMaxReduceBlocks partials + 4 result words
-    int64_t* host = nullptr;   // 4 words, pinned
+    int64_t* host = nullptr;   // 4 words, pinned (coherent): the synchronous-result entry points let the last kernel write
+                               // its result straight into them — no device-to-host copy is queued behind the kernel
+    int64_t* host_dev = nullptr;  // the same words as the device addresses them
     std::mutex* mu = nullptr;
     int64_t* dev_result() const { return dev + 2 * kMaxReduceBlocks; }
 };
