@@ -406,7 +406,8 @@ def test_config5_ndvi_in_one_process_over_a_shard_group(ec, golden_dir, G):
 
 def _build_example(tmp_path, name):
     exe = str(tmp_path / name)
-    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1", "-I" + os.path.join(ROOT, "include"),
+    r = subprocess.run(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1",
+                        "-I" + os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "examples", name + ".c"), "-L" + LIBDIR, "-lerased_cells_hip",
                         "-Wl,-rpath," + LIBDIR, "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -423,3 +424,22 @@ def test_runtime_lifecycle_init_shutdown_init_from_plain_c(tmp_path):
     r = subprocess.run([_build_example(tmp_path, "lifecycle")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.split() == ["round", "0", "ok", "round", "1", "ok", "round", "2", "ok"]
+
+
+def test_rank_example_is_plain_c99_and_links(tmp_path):
+    _build_example(tmp_path, "rank")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_one_process_per_gpu_shape_without_torch(tmp_path):
+    """examples/rank.c: the one-process-per-GPU shape through the ABI's own communicator bootstrap (unique id handed
+    over in a file).  One GPU allows one rank; its answers are the whole raster's, recomputed by the oracle."""
+    rows, cols = 257, 1021
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([_build_example(tmp_path, "rank"), str(tmp_path / "ec.uid"), "1", "0", "0", str(rows), str(cols)],
+                       capture_output=True, text=True, timeout=250, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("rank 0: ")]
+    assert lines == ["rank 0: " + _expected(rows, cols, 1)], r.stdout
+    assert not (tmp_path / "ec.uid").exists()
