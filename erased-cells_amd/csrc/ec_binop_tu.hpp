@@ -16,9 +16,7 @@ static ec_status launch_binop_pair(const void* l, const void* r, size_t n, doubl
     const Tuning& tu = tuning();
     const L* lp = static_cast<const L*>(l);
     const R* rp = static_cast<const R*>(r);
-    // tile depth: 2 for every operand width but two 2-byte operands, where 1 is 3 % faster (u16 + u16: 0.792 of peak
-    // against 0.769 at depth 2 on one box, profiles/r02/tune_binop_u.log) — the usual raster cell type
-    constexpr int U = (sizeof(L) == 2 && sizeof(R) == 2) ? 1 : kBinopU;
+    constexpr int U = kBinopU;
     if (!aligned16(l, r, out)) {
         k_binop_cellwise<L, R, OP><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(lp, rp, out, n);
         return check_launch("binop(cellwise)");
