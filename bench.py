@@ -357,6 +357,9 @@ def main():
         keys = torch.empty(2, dtype=torch.int64, device="cuda")
         bytes_per_cell, kernel = 2, "k_min_max_partials<u16>"
         wl = f"{side}x{side} u16 min_max, row-sharded, all-reduce of 2 int64 keys (BASELINE configs[3] shape)"
+        if side == 65536:
+            wl += (f"; configs[3]'s whole 8.6 GB raster, {rows_total // world} rows per rank" +
+                   (" - on ONE GPU here; at 8 GPUs a rank's shard is 8192 x 65536 cells, 1.07 GB" if world == 1 else ""))
 
         def step():
             chk(L.ec_min_max_keys(ec.UInt16, a.mem.ptr, None, n, keys.data_ptr(), stream))
