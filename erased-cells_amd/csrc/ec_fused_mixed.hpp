@@ -21,7 +21,7 @@
 
 namespace ecd {
 
-// ordered (A, B) pairs: both orders of (u16, f32), (u8, u16), (i16, f32), (f32, f64)
+// ordered (A, B) pairs: both orders of (u16, f32), (u8, u16), (i16, f32), (f32, f64), (u8, f32), (u16, i16)
 #define EC_FUSED_MIXED_PAIRS(X)        \
     X(0, EC_U16, uint16_t, EC_F32, float)   \
     X(1, EC_F32, float, EC_U16, uint16_t)   \
@@ -30,8 +30,12 @@ namespace ecd {
     X(4, EC_I16, int16_t, EC_F32, float)    \
     X(5, EC_F32, float, EC_I16, int16_t)    \
     X(6, EC_F32, float, EC_F64, double)     \
-    X(7, EC_F64, double, EC_F32, float)
-constexpr int kFusedMixedPairs = 8;
+    X(7, EC_F64, double, EC_F32, float)     \
+    X(8, EC_U8, uint8_t, EC_F32, float)     \
+    X(9, EC_F32, float, EC_U8, uint8_t)     \
+    X(10, EC_U16, uint16_t, EC_I16, int16_t) \
+    X(11, EC_I16, int16_t, EC_U16, uint16_t)
+constexpr int kFusedMixedPairs = 12;
 
 // slot patterns: bit k set = slot k (x, y, z, w) has type B
 constexpr int kPatABAB = 0b1010;  // four operands

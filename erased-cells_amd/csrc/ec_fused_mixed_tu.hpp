@@ -1,6 +1,6 @@
 // ec_fused_mixed_tu.hpp — launchers of the mixed-type fused kernels for one outer op O2:
-// 8 ordered type pairs x (A B A B: 4 inner ops x 4 second-term ops  +  3 three-operand patterns x 4 inner ops)
-// = 224 kernels; ec_fusedx_{add,sub,mul,div}.hip instantiate one each.
+// 12 ordered type pairs x (A B A B: 4 inner ops x 4 second-term ops  +  3 three-operand patterns x 4 inner ops)
+// = 336 kernels; ec_fusedx_{add,sub,mul,div}.hip instantiate one each.
 #pragma once
 
 #include <hip/hip_runtime.h>

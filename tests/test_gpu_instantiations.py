@@ -121,7 +121,8 @@ def test_fused_every_op_triple(ec, pool, ct):
 
 
 MIXED_PAIRS = [(eco.U16, eco.F32), (eco.F32, eco.U16), (eco.U8, eco.U16), (eco.U16, eco.U8),
-               (eco.I16, eco.F32), (eco.F32, eco.I16), (eco.F32, eco.F64), (eco.F64, eco.F32)]
+               (eco.I16, eco.F32), (eco.F32, eco.I16), (eco.F32, eco.F64), (eco.F64, eco.F32),
+               (eco.U8, eco.F32), (eco.F32, eco.U8), (eco.U16, eco.I16), (eco.I16, eco.U16)]
 
 
 def _pool_allocs(ec):
