@@ -58,29 +58,25 @@ __device__ __forceinline__ size_t two_front_tile() {
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const R* __restrict__ r,
                                                   double* __restrict__ out, size_t npairs, size_t tile) {
-    using L2 = vec<L, 2>;
-    using R2 = vec<R, 2>;
     using D2 = vec<double, 2>;
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
     constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
     constexpr size_t TILE = size_t(kBlock) * U;
-    const L2* __restrict__ lp = reinterpret_cast<const L2*>(l);
-    const R2* __restrict__ rp = reinterpret_cast<const R2*>(r);
     D2* __restrict__ op = reinterpret_cast<D2*>(out);
     const size_t base = tile * TILE + threadIdx.x;
     if (tile * TILE + TILE <= npairs) {
-        L2 a[U];
-        R2 b[U];
+        cells<L, 2> a[U];  // 1-byte operands travel as 16-bit words so that their loads keep `nt` (ec_device.hpp)
+        cells<R, 2> b[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            a[j] = load_vec<NT_LD>(lp + base + size_t(j) * kBlock);
-            b[j] = load_vec<NT_LD>(rp + base + size_t(j) * kBlock);
+            a[j] = load_cells<NT_LD, L, 2>(l + 2 * (base + size_t(j) * kBlock));
+            b[j] = load_cells<NT_LD, R, 2>(r + 2 * (base + size_t(j) * kBlock));
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             D2 o;
-            o.x = cell_op<OP, FP, SM>(to_f64(a[j].x), to_f64(b[j].x));
-            o.y = cell_op<OP, FP, SM>(to_f64(a[j].y), to_f64(b[j].y));
+            o.x = cell_op<OP, FP, SM>(to_f64(a[j][0]), to_f64(b[j][0]));
+            o.y = cell_op<OP, FP, SM>(to_f64(a[j][1]), to_f64(b[j][1]));
             store_vec<NT_ST>(op + base + size_t(j) * kBlock, o);
         }
     } else {
@@ -88,12 +84,12 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
         for (int j = 0; j < U; ++j) {
             const size_t p = base + size_t(j) * kBlock;
             if (p < npairs) {
-                L2 a = plain_load(lp + p);
-                R2 b = plain_load(rp + p);
+                const cells<L, 2> a = load_cells<NT_LD, L, 2>(l + 2 * p);
+                const cells<R, 2> b = load_cells<NT_LD, R, 2>(r + 2 * p);
                 D2 o;
-                o.x = cell_op<OP, FP, SM>(to_f64(a.x), to_f64(b.x));
-                o.y = cell_op<OP, FP, SM>(to_f64(a.y), to_f64(b.y));
-                plain_store(o, op + p);
+                o.x = cell_op<OP, FP, SM>(to_f64(a[0]), to_f64(b[0]));
+                o.y = cell_op<OP, FP, SM>(to_f64(a[1]), to_f64(b[1]));
+                store_vec<NT_ST>(op + p, o);
             }
         }
     }
@@ -111,7 +107,8 @@ __device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
     constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
     if (head) {
-        if (blockIdx.x == 0 && threadIdx.x < head) out[threadIdx.x] = cell_op<OP, FP, SM>(to_f64(l[threadIdx.x]), to_f64(r[threadIdx.x]));
+        if (blockIdx.x == 0 && threadIdx.x < head)
+            st_cell(cell_op<OP, FP, SM>(to_f64(ld_cell(l + threadIdx.x)), to_f64(ld_cell(r + threadIdx.x))), out + threadIdx.x);
         l += head;
         r += head;
         out += head;
@@ -119,28 +116,26 @@ __device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const
     }
     binop_direct_tile<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n >> 1, two_front_tile());
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
-        out[n - 1] = cell_op<OP, FP, SM>(to_f64(l[n - 1]), to_f64(r[n - 1]));
+        st_cell(cell_op<OP, FP, SM>(to_f64(ld_cell(l + n - 1)), to_f64(ld_cell(r + n - 1))), out + n - 1);
 }
 
 template <typename L, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, double s, double* __restrict__ out,
                                                   size_t npairs, size_t tile) {
-    using L2 = vec<L, 2>;
     using D2 = vec<double, 2>;
     constexpr bool FP = true;  // the scalar may be any of the 10 types, widened to f64 on the host
     constexpr size_t TILE = size_t(kBlock) * U;
-    const L2* __restrict__ lp = reinterpret_cast<const L2*>(l);
     D2* __restrict__ op = reinterpret_cast<D2*>(out);
     const size_t base = tile * TILE + threadIdx.x;
     if (tile * TILE + TILE <= npairs) {
-        L2 a[U];
+        cells<L, 2> a[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) a[j] = load_vec<NT_LD>(lp + base + size_t(j) * kBlock);
+        for (int j = 0; j < U; ++j) a[j] = load_cells<NT_LD, L, 2>(l + 2 * (base + size_t(j) * kBlock));
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             D2 o;
-            o.x = cell_op<OP, FP>(to_f64(a[j].x), s);
-            o.y = cell_op<OP, FP>(to_f64(a[j].y), s);
+            o.x = cell_op<OP, FP>(to_f64(a[j][0]), s);
+            o.y = cell_op<OP, FP>(to_f64(a[j][1]), s);
             store_vec<NT_ST>(op + base + size_t(j) * kBlock, o);
         }
     } else {
@@ -148,11 +143,11 @@ __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, doubl
         for (int j = 0; j < U; ++j) {
             const size_t p = base + size_t(j) * kBlock;
             if (p < npairs) {
-                L2 a = plain_load(lp + p);
+                const cells<L, 2> a = load_cells<NT_LD, L, 2>(l + 2 * p);
                 D2 o;
-                o.x = cell_op<OP, FP>(to_f64(a.x), s);
-                o.y = cell_op<OP, FP>(to_f64(a.y), s);
-                plain_store(o, op + p);
+                o.x = cell_op<OP, FP>(to_f64(a[0]), s);
+                o.y = cell_op<OP, FP>(to_f64(a[1]), s);
+                store_vec<NT_ST>(op + p, o);
             }
         }
     }
@@ -162,13 +157,13 @@ template <typename L, int OP, int U, bool NT_ST, bool NT_LD>
 __global__ __launch_bounds__(kBlock) void k_binop_scalar_direct(const L* __restrict__ l, double s,
                                                                 double* __restrict__ out, size_t n, unsigned head) {
     if (head) {  // see binop_direct_body
-        if (blockIdx.x == 0 && threadIdx.x < head) out[threadIdx.x] = cell_op<OP, true>(to_f64(l[threadIdx.x]), s);
+        if (blockIdx.x == 0 && threadIdx.x < head) st_cell(cell_op<OP, true>(to_f64(ld_cell(l + threadIdx.x)), s), out + threadIdx.x);
         l += head;
         out += head;
         n -= head;
     }
     binop_scalar_tile<L, OP, U, NT_ST, NT_LD>(l, s, out, n >> 1, two_front_tile());
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[n - 1] = cell_op<OP, true>(to_f64(l[n - 1]), s);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) st_cell(cell_op<OP, true>(to_f64(ld_cell(l + n - 1)), s), out + n - 1);
 }
 
 // Any alignment, any n: one cell per lane. Correctness fallback for odd offsets.
@@ -274,7 +269,7 @@ __device__ __forceinline__ void binop_lds_body(const L* __restrict__ l, const R*
     // ragged tail (< one wave tile): cell-wise by workgroup 0
     if (blockIdx.x == 0)
         for (size_t i = nfull * kLdsWaveCells + threadIdx.x; i < n; i += kBlock)
-            out[i] = cell_op<OP, FP, SM>(to_f64(l[i]), to_f64(r[i]));
+            st_cell(cell_op<OP, FP, SM>(to_f64(ld_cell(l + i)), to_f64(ld_cell(r + i))), out + i);
 }
 
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
@@ -300,7 +295,7 @@ __device__ __forceinline__ void mask_and_body(const uint8_t* __restrict__ lm, co
     for (size_t g = size_t(blockIdx.x) * kBlock + threadIdx.x; g < ngroups; g += stride)
         nt_store(nt_load(a + g) & nt_load(b + g), o + g);
     if (blockIdx.x == 0)
-        for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) om[i] = lm[i] & rm[i];
+        for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) st_cell<uint8_t>(ld_cell(lm + i) & ld_cell(rm + i), om + i);
 }
 
 // impl $trt for &MaskedCellBuffer (src/masked/masked_buffer.rs:326-335) in one

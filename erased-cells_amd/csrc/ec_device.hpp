@@ -161,5 +161,53 @@ __device__ __forceinline__ void plain_store(V v, V* p) {
     *reinterpret_cast<typename under_aligned<V>::type*>(p) = v;
 }
 
+// One cell (the peeled head cell, the odd tail cell, the ragged tail of a tile grid): non-temporal like every other
+// access to caller data, so that "every load and store of a streaming kernel carries nt" holds without exceptions
+// (tools/isa_audit.py).  Scalar accesses keep the flag at every width.
+template <typename T>
+__device__ __forceinline__ T ld_cell(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void st_cell(T v, T* p) { __builtin_nontemporal_store(v, p); }
+
+// N cells of type T as one lane loads them.  Cells of 2 bytes and more are the typed vector.  1-BYTE cells travel as
+// unsigned words (uint16_t, uint32_t, 2 or 4 dwords) and are picked apart with shifts: hipcc (ROCm 7.2) drops the
+// non-temporal flag from loads of <N x i8> vectors when it legalises them — every u8 / i8 / mask stream of rounds 1-2
+// was loaded with plain `global_load_ushort/dword/dwordx2/dwordx4` while all other streams carried `nt` — and a
+// bit-cast of a loaded word to <N x i8> is folded back into such a load.  As words the loads keep `nt`
+// (tools/isa_audit.py checks every full-tile load of the library; A/B in profiles/r03/nt_u8_ab.md).
+template <int N> struct byte_words;
+template <> struct byte_words<2> { using type = uint16_t; };
+template <> struct byte_words<4> { using type = uint32_t; };
+template <> struct byte_words<8> { using type = vec<uint32_t, 2>; };
+template <> struct byte_words<16> { using type = vec<uint32_t, 4>; };
+
+template <typename T, int N, bool BYTES = sizeof(T) == 1>
+struct cells {  // 2-, 4-, 8-byte cells
+    using rep = vec<T, N>;
+    rep v;
+    __device__ __forceinline__ T operator[](int k) const { return v[k]; }
+};
+template <typename T, int N>
+struct cells<T, N, true> {  // 1-byte cells
+    using rep = typename byte_words<N>::type;
+    rep v;
+    __device__ __forceinline__ T operator[](int k) const {
+        uint32_t w;
+        if constexpr (N <= 4) w = static_cast<uint32_t>(v);
+        else w = v[k >> 2];
+        // signed cells by shift-left / arithmetic-shift-right (one v_bfe_i32): a mask-and-truncate chain of i8 cells is
+        // recognised as a <N x i8> sign extension and folded back into a vector load (ConvertFn<i8, i16> did)
+        if constexpr (T(-1) < T(0)) return static_cast<T>(static_cast<int32_t>(w << (24 - 8 * (k & 3))) >> 24);
+        else return static_cast<T>((w >> (8 * (k & 3))) & 0xffu);
+    }
+};
+template <bool NT, typename T, int N>
+__device__ __forceinline__ cells<T, N> load_cells(const T* first_cell) {
+    using C = cells<T, N>;
+    const typename C::rep* p = reinterpret_cast<const typename C::rep*>(first_cell);
+    if constexpr (NT) return C{nt_load(p)};
+    else return C{plain_load(p)};
+}
+
 
 }  // namespace ecd

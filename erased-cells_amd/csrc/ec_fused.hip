@@ -1,75 +1,59 @@
-// ec_fused.hip — ABI entry points of the fused two-level expression kernels (ec_fused_kernels.hpp, ec_fused_mixed.hpp):
-// operand set-up (aliases, scalars, masks), dispatch by op triple; operands of two cell types run the per-slot typed
-// one-pass kernel where one is instantiated, other mixes are unified (converted) first.
+// ec_fused.hip — ABI entry points of the fused two-level expression kernels: operand set-up (aliases, scalars, masks) and
+// dispatch.  Buffer operands of ONE cell type run the kernels specialised per type and op triple (ec_fused_kernels.hpp);
+// every other mix of cell types runs k_fused_any (ec_fused_any.hpp: load classes at compile time, kinds and ops
+// launch-uniform) — one pass, no temporaries, for all of them.
 #include <hip/hip_runtime.h>
 
-#include "ec_fused_mixed.hpp"
+#include "ec_fused_any.hpp"
 #include "ec_lattice.hpp"
 #include "ec_runtime.hpp"
 
 namespace ecd {
 template <int O2>
 void dispatch_fused(const FusedArgs& fa, int same_dt, unsigned grid, double* out, uint8_t* out_mask, size_t n, hipStream_t s);
-template <int O2>
-bool dispatch_fused_mixed(const FusedArgs& fa, int pair, int pat, unsigned grid, double* out, uint8_t* om, size_t n, hipStream_t s);
 }
 
 using namespace ecd;
 
-// Buffer operands of exactly two cell types: the one-pass kernel with per-slot typed loads (ec_fused_mixed.hpp), if
-// one is instantiated for this (ordered type pair, slot pattern).  Returns true when it was launched.
-static bool try_fused_mixed(FusedArgs& fa, int nops, size_t n, double* out, uint8_t* out_mask, hipStream_t s) {
-    int types[2] = {-1, -1}, nt = 0;
-    for (int k = 0; k < nops; ++k) {
-        if (fa.is_sc[k]) continue;
-        const int t = fa.dt[k];
-        if (nt > 0 && t == types[0]) continue;
-        if (nt > 1 && t == types[1]) continue;
-        if (nt == 2) return false;  // three cell types
-        types[nt++] = t;
-    }
-    if (nt != 2) return false;
-    static const int kPairs[kFusedMixedPairs][2] = {
-#define EC_ROW(IDX, AID, AT, BID, BT) {AID, BID},
-        EC_FUSED_MIXED_PAIRS(EC_ROW)
-#undef EC_ROW
-    };
-    static const int kPats4[] = {kPatABAB};
-    static const int kPats3[] = {kPatAAB, kPatABA, kPatABB};
-    const int* pats = nops == 4 ? kPats4 : kPats3;
-    const int npats = nops == 4 ? 1 : 3;
-    for (int order = 0; order < 2; ++order) {
-        const int A = types[order], B = types[1 - order];
-        int pair = -1;
-        for (int i = 0; i < kFusedMixedPairs; ++i)
-            if (kPairs[i][0] == A && kPairs[i][1] == B) pair = i;
-        if (pair < 0) continue;
-        for (int pi = 0; pi < npats; ++pi) {
-            const int pat = pats[pi];
-            bool fits = true;
-            for (int k = 0; k < nops && fits; ++k)
-                if (!fa.is_sc[k]) fits = (fa.dt[k] == B) == (((pat >> k) & 1) != 0);  // a scalar fits any slot
-            if (!fits) continue;
-            // peel one leading cell when that puts more of the 1-byte operands on even addresses (peel_head's rule)
-            unsigned c0 = 0, c1 = 0;
-            for (int k = 0; k < nops; ++k)
-                if (!fa.is_sc[k] && fa.alias[k] == k) {
-                    c0 += peel_cost(fa.p[k], ecl::size_of(fa.dt[k]), 0);
-                    c1 += peel_cost(fa.p[k], ecl::size_of(fa.dt[k]), 1);
-                }
-            fa.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
-            const size_t sa = ecl::size_of(A), sb = ecl::size_of(B);
-            const size_t per_tile = size_t(kBlock) * fused_u(sa < sb ? sa : sb);
-            const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
-            switch (fa.o2) {
-                case EC_ADD: return dispatch_fused_mixed<EC_ADD>(fa, pair, pat, grid, out, out_mask, n, s);
-                case EC_SUB: return dispatch_fused_mixed<EC_SUB>(fa, pair, pat, grid, out, out_mask, n, s);
-                case EC_MUL: return dispatch_fused_mixed<EC_MUL>(fa, pair, pat, grid, out, out_mask, n, s);
-                default: return dispatch_fused_mixed<EC_DIV>(fa, pair, pat, grid, out, out_mask, n, s);
-            }
+// peel one leading cell when that puts more of the 1-byte operand streams on even addresses (peel_head's rule)
+static unsigned fused_head(const FusedArgs& fa, size_t n) {
+    unsigned c0 = 0, c1 = 0;
+    for (int k = 0; k < 4; ++k)
+        if (!fa.is_sc[k] && fa.alias[k] == k) {
+            c0 += peel_cost(fa.p[k], ecl::size_of(fa.dt[k]), 0);
+            c1 += peel_cost(fa.p[k], ecl::size_of(fa.dt[k]), 1);
         }
+    return (n >= 2 && tuning().peel && c1 < c0) ? 1u : 0u;
+}
+
+// Any mix of operand cell types in one pass: the kernel is picked by the byte width of each slot's own stream
+// (0: the slot is a scalar, an alias of an earlier slot, or the unused w of a three-operand chain).
+static ec_status launch_fused_any(FusedArgs& fa, int nops, size_t n, double* out, uint8_t* out_mask, hipStream_t s) {
+    int cls[4];
+    bool small = fa.o2 == EC_DIV && (fa.o1 == EC_ADD || fa.o1 == EC_SUB) && (fa.o3 == EC_ADD || fa.o3 == EC_SUB || fa.o3 == kOpNone);
+    size_t narrowest = 8;
+    for (int k = 0; k < 4; ++k) {
+        const bool own = k < nops && !fa.is_sc[k] && fa.alias[k] == k;
+        const size_t bytes = own ? ecl::size_of(fa.dt[k]) : 0;
+        cls[k] = fused_class_index(bytes);
+        if (own && bytes < narrowest) narrowest = bytes;
+        if (k < nops) small = small && !fa.is_sc[k] && ecl::is_integral(fa.dt[k]) && ecl::size_of(fa.dt[k]) <= 2;
     }
-    return false;
+    fa.small = small ? 1 : 0;
+    fa.head = static_cast<uint8_t>(fused_head(fa, n));
+    const size_t per_tile = size_t(kBlock) * fused_u(narrowest);
+    const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
+    FusedAnyKernel kern = nullptr;
+    switch (cls[0]) {
+        case 0: kern = fused_any_kernel<0>(cls[1], cls[2], cls[3]); break;
+        case 1: kern = fused_any_kernel<1>(cls[1], cls[2], cls[3]); break;
+        case 2: kern = fused_any_kernel<2>(cls[1], cls[2], cls[3]); break;
+        case 3: kern = fused_any_kernel<4>(cls[1], cls[2], cls[3]); break;
+        default: kern = fused_any_kernel<8>(cls[1], cls[2], cls[3]); break;
+    }
+    if (!kern) return set_error(EC_ERR_ARG, "ec_fused: no kernel for load classes %d %d %d %d", cls[0], cls[1], cls[2], cls[3]);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fa, out, out_mask, n);
+    return check_launch("fused(any)");
 }
 
 static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], const void* const p[4],
@@ -123,11 +107,16 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         k_fused_cellwise<0><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fa, out, out_mask, n);
         return check_launch("fused(cellwise)");
     }
-    if (tuning().fused_mixed && try_fused_mixed(fa, nops, n, out, out_mask, s)) return check_launch("fused(mixed)");
+    bool same_type = true;
+    for (int k = 0; k < 4; ++k)
+        if (!fa.is_sc[k] && fa.dt[k] != fa.dt[first_buf]) same_type = false;
+    const int mixed_mode = tuning().fused_mixed;  // 1 (default): k_fused_any for mixed cell types; 2: for every call; 0: convert, then fuse
+    if (mixed_mode == 2 || (mixed_mode == 1 && !same_type)) return launch_fused_any(fa, nops, n, out, out_mask, s);
     fa.head = 0;
-    // Other mixes of operand types: widen every buffer operand to the common CellType::union first (the
-    // reference's `unify`, value-preserving — SURVEY App. A.1) into temporaries from the stream-ordered
-    // pool, then run the same-type kernel.  Same-type calls allocate nothing.
+    // fused_mixed == 0 — the comparison path of rounds 1-2, kept for A/B runs and as a second implementation the tests
+    // hold k_fused_any against: widen every buffer operand to the common CellType::union first (the reference's
+    // `unify`, value-preserving — SURVEY App. A.1) into temporaries from the stream-ordered pool, then run the same-type
+    // kernel.  Same-type calls convert and allocate nothing.
     int u = fa.dt[first_buf];
     for (int k = 0; k < 4; ++k)
         if (!fa.is_sc[k]) u = ecl::union_of(u, fa.dt[k]);
@@ -147,11 +136,7 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         fa.dt[k] = static_cast<int8_t>(u);
     }
     if (st == EC_OK) {
-        // peel one leading cell when that puts more of the (now same-typed) 1-byte operands on even addresses
-        unsigned c0 = 0, c1 = 0;
-        for (int k = 0; k < 4; ++k)
-            if (!fa.is_sc[k] && fa.alias[k] == k) { c0 += peel_cost(fa.p[k], ecl::size_of(u), 0); c1 += peel_cost(fa.p[k], ecl::size_of(u), 1); }
-        fa.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
+        fa.head = static_cast<uint8_t>(fused_head(fa, n));  // (operands are same-typed by now)
         const size_t per_tile = size_t(kBlock) * fused_u(ecl::size_of(u));
         const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
         switch (o2) {

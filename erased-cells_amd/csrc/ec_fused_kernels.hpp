@@ -35,11 +35,12 @@ struct FusedArgs {
     int8_t is_sc[4];         // operand k is a scalar constant (no stream): value sc[k]
     uint8_t head;            // leading cells (0/1) computed singly so the pair loads of 1-byte cells start on even
                              // addresses (peel_head, ec_runtime.hpp); vector kernel only
+    uint8_t small;           // k_fused_any only: NDVI shape over ≤16-bit integer buffers (ec_fused_any.hpp)
     double sc[4];
 };
 
 template <typename T>
-__device__ __forceinline__ double load_cell_as(const void* p, size_t i) { return to_f64(static_cast<const T*>(p)[i]); }
+__device__ __forceinline__ double load_cell_as(const void* p, size_t i) { return to_f64(ld_cell(static_cast<const T*>(p) + i)); }
 
 __device__ __forceinline__ double load_cell_f64(const void* p, int dt, size_t i) {
     switch (dt) {
@@ -120,9 +121,9 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
         }
         if (blockIdx.x == 0)
             for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) {
-                uint8_t acc = fa.m[0][i];
-                for (int k = 1; k < fa.nmask; ++k) acc &= fa.m[k][i];
-                out_mask[i] = acc;
+                uint8_t acc = ld_cell(fa.m[0] + i);
+                for (int k = 1; k < fa.nmask; ++k) acc &= ld_cell(fa.m[k] + i);
+                st_cell(acc, out_mask + i);
             }
     }
 }
@@ -137,33 +138,33 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
 // config 3 0.764 against 0.778 and (a+b)*c on f32 0.782 against 0.797 — these kernels wait on HBM, not on their
 // instruction count.  The code stays behind EC_FUSED_FAST_TILES (off) so the comparison can be repeated.
 template <typename TX, typename TY, typename TZ, typename TW, int O1, int O2, int O3, int U, bool NDVI>
-__device__ __forceinline__ void fused_fast_tile(const vec<TX, 2>* __restrict__ px, const vec<TY, 2>* __restrict__ py,
-                                                const vec<TZ, 2>* __restrict__ pz, const vec<TW, 2>* __restrict__ pw,
+__device__ __forceinline__ void fused_fast_tile(const TX* __restrict__ px, const TY* __restrict__ py,
+                                                const TZ* __restrict__ pz, const TW* __restrict__ pw,
                                                 D2* __restrict__ op, size_t base) {
     constexpr bool has_w = O3 != kOpNone;
     constexpr bool kSmall = is_small_int<TX>::value && is_small_int<TY>::value && is_small_int<TZ>::value &&
                             (!has_w || is_small_int<TW>::value) && is_ndvi_shape<O1, O2, O3>::value;
-    vec<TX, 2> x[U];
-    vec<TY, 2> y[U];
-    vec<TZ, 2> z[U] = {};
-    vec<TW, 2> w[U] = {};
+    cells<TX, 2> x[U];
+    cells<TY, 2> y[U];
+    cells<TZ, 2> z[U] = {};
+    cells<TW, 2> w[U] = {};
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         const size_t pr = base + size_t(j) * kBlock;
-        x[j] = nt_load(px + pr);
-        y[j] = nt_load(py + pr);
+        x[j] = load_cells<true, TX, 2>(px + 2 * pr);
+        y[j] = load_cells<true, TY, 2>(py + 2 * pr);
         if constexpr (!NDVI) {
-            z[j] = nt_load(pz + pr);
-            if constexpr (has_w) w[j] = nt_load(pw + pr);
+            z[j] = load_cells<true, TZ, 2>(pz + 2 * pr);
+            if constexpr (has_w) w[j] = load_cells<true, TW, 2>(pw + 2 * pr);
         }
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-        const D2 vx{to_f64(x[j].x), to_f64(x[j].y)}, vy{to_f64(y[j].x), to_f64(y[j].y)};
+        const D2 vx{to_f64(x[j][0]), to_f64(x[j][1])}, vy{to_f64(y[j][0]), to_f64(y[j][1])};
         D2 vz = vx, vw = vy;  // NDVI: z is x, w is y
         if constexpr (!NDVI) {
-            vz = D2{to_f64(z[j].x), to_f64(z[j].y)};
-            if constexpr (has_w) vw = D2{to_f64(w[j].x), to_f64(w[j].y)};
+            vz = D2{to_f64(z[j][0]), to_f64(z[j][1])};
+            if constexpr (has_w) vw = D2{to_f64(w[j][0]), to_f64(w[j][1])};
         }
         D2 o;
         if constexpr (kSmall) {
@@ -194,7 +195,7 @@ __device__ __forceinline__ int fused_fast_config(const FusedArgs& fa) {
 // operands have cell type T.
 template <typename T, int O1, int O2, int O3>
 __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
-    using T2 = vec<T, 2>;
+    using T2 = cells<T, 2>;  // 1-byte cells as a 16-bit word, so that the pair loads keep `nt` (ec_device.hpp)
     constexpr int kFusedU = fused_u(sizeof(T));
     const unsigned head = fa.head;
     const size_t npairs = (n - head) >> 1;
@@ -203,10 +204,10 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
     const size_t base = tile * TILE + threadIdx.x;
     constexpr bool has_w = O3 != kOpNone;
     D2* __restrict__ op = reinterpret_cast<D2*>(out + head);
-    const T2* __restrict__ px = reinterpret_cast<const T2*>(static_cast<const T*>(fa.p[0]) + head);
-    const T2* __restrict__ py = reinterpret_cast<const T2*>(static_cast<const T*>(fa.p[1]) + head);
-    const T2* __restrict__ pz = reinterpret_cast<const T2*>(static_cast<const T*>(fa.p[2]) + head);
-    const T2* __restrict__ pw = reinterpret_cast<const T2*>(static_cast<const T*>(fa.p[3]) + head);
+    const T* __restrict__ px = static_cast<const T*>(fa.p[0]) + head;
+    const T* __restrict__ py = static_cast<const T*>(fa.p[1]) + head;
+    const T* __restrict__ pz = static_cast<const T*>(fa.p[2]) + head;
+    const T* __restrict__ pw = static_cast<const T*>(fa.p[3]) + head;
     // launch-uniform operand configuration, resolved once per wave
     const bool ld_x = !fa.is_sc[0], ld_y = !fa.is_sc[1] && fa.alias[1] == 1, ld_z = !fa.is_sc[2] && fa.alias[2] == 2,
                ld_w = has_w && !fa.is_sc[3] && fa.alias[3] == 3;
@@ -224,10 +225,10 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
     for (int j = 0; j < kFusedU; ++j) {
         const size_t pr = base + size_t(j) * kBlock;
         if (full || pr < npairs) {
-            if (ld_x) x[j] = nt_load(px + pr);
-            if (ld_y) y[j] = nt_load(py + pr);
-            if (ld_z) z[j] = nt_load(pz + pr);
-            if (ld_w) w[j] = nt_load(pw + pr);
+            if (ld_x) x[j] = load_cells<true, T, 2>(px + 2 * pr);
+            if (ld_y) y[j] = load_cells<true, T, 2>(py + 2 * pr);
+            if (ld_z) z[j] = load_cells<true, T, 2>(pz + 2 * pr);
+            if (ld_w) w[j] = load_cells<true, T, 2>(pw + 2 * pr);
         }
     }
 #pragma unroll
@@ -237,10 +238,10 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
             const T2 yy = fa.alias[1] == 1 ? y[j] : x[j];
             const T2 zz = fa.alias[2] == 2 ? z[j] : (fa.alias[2] == 0 ? x[j] : yy);
             const T2 ww = !has_w ? zz : fa.alias[3] == 3 ? w[j] : (fa.alias[3] == 0 ? x[j] : fa.alias[3] == 1 ? yy : zz);
-            const D2 vx = fa.is_sc[0] ? D2{fa.sc[0], fa.sc[0]} : D2{to_f64(x[j].x), to_f64(x[j].y)};
-            const D2 vy = fa.is_sc[1] ? D2{fa.sc[1], fa.sc[1]} : D2{to_f64(yy.x), to_f64(yy.y)};
-            const D2 vz = fa.is_sc[2] ? D2{fa.sc[2], fa.sc[2]} : D2{to_f64(zz.x), to_f64(zz.y)};
-            const D2 vw = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : D2{to_f64(ww.x), to_f64(ww.y)};
+            const D2 vx = fa.is_sc[0] ? D2{fa.sc[0], fa.sc[0]} : D2{to_f64(x[j][0]), to_f64(x[j][1])};
+            const D2 vy = fa.is_sc[1] ? D2{fa.sc[1], fa.sc[1]} : D2{to_f64(yy[0]), to_f64(yy[1])};
+            const D2 vz = fa.is_sc[2] ? D2{fa.sc[2], fa.sc[2]} : D2{to_f64(zz[0]), to_f64(zz[1])};
+            const D2 vw = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : D2{to_f64(ww[0]), to_f64(ww[1])};
             D2 o;
             if (small_ints) {  // launch-uniform
                 if constexpr (kSmallShape) {
@@ -259,8 +260,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_same(FusedArgs fa, double* __r
         const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;
         const size_t i = threadIdx.x == 0 ? 0 : n - 1;
         if (do_it)
-            out[i] = fused_cell_t<O1, O2, O3>(operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
-                                              has_w ? operand_cell(fa, 3, i) : 0.0);
+            st_cell(fused_cell_t<O1, O2, O3>(operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
+                                             has_w ? operand_cell(fa, 3, i) : 0.0), out + i);
     }
     fused_mask_phase(fa, out_mask, n);
 }

@@ -44,7 +44,7 @@ constexpr int kPatABA = 0b0010;
 constexpr int kPatABB = 0b0110;
 
 template <typename Own, typename C>
-__device__ __forceinline__ vec<Own, 2> same_or(const vec<Own, 2>& own, const vec<C, 2>& cand, bool take) {
+__device__ __forceinline__ cells<Own, 2> same_or(const cells<Own, 2>& own, const cells<C, 2>& cand, bool take) {
     if constexpr (std::is_same<Own, C>::value) return take ? cand : own;
     else { (void)cand; (void)take; return own; }  // the host never aliases slots of different cell types
 }
@@ -55,10 +55,10 @@ __global__ __launch_bounds__(kBlock) void k_fused_mixed(FusedArgs fa, double* __
     using TY = typename std::conditional<(PAT & 2) != 0, B, A>::type;
     using TZ = typename std::conditional<(PAT & 4) != 0, B, A>::type;
     using TW = typename std::conditional<(PAT & 8) != 0, B, A>::type;
-    using X2 = vec<TX, 2>;
-    using Y2 = vec<TY, 2>;
-    using Z2 = vec<TZ, 2>;
-    using W2 = vec<TW, 2>;
+    using X2 = cells<TX, 2>;
+    using Y2 = cells<TY, 2>;
+    using Z2 = cells<TZ, 2>;
+    using W2 = cells<TW, 2>;
     constexpr int kFusedU = fused_u(sizeof(A) < sizeof(B) ? sizeof(A) : sizeof(B));  // by the NARROWER type: u16 + f32 runs the same at 2 and 4, f32 + f64 wants 2
     const unsigned head = fa.head;
     const size_t npairs = (n - head) >> 1;
@@ -67,10 +67,10 @@ __global__ __launch_bounds__(kBlock) void k_fused_mixed(FusedArgs fa, double* __
     const size_t base = tile * TILE + threadIdx.x;
     constexpr bool has_w = O3 != kOpNone;
     D2* __restrict__ op = reinterpret_cast<D2*>(out + head);
-    const X2* __restrict__ px = reinterpret_cast<const X2*>(static_cast<const TX*>(fa.p[0]) + head);
-    const Y2* __restrict__ py = reinterpret_cast<const Y2*>(static_cast<const TY*>(fa.p[1]) + head);
-    const Z2* __restrict__ pz = reinterpret_cast<const Z2*>(static_cast<const TZ*>(fa.p[2]) + head);
-    const W2* __restrict__ pw = reinterpret_cast<const W2*>(static_cast<const TW*>(fa.p[3]) + head);
+    const TX* __restrict__ px = static_cast<const TX*>(fa.p[0]) + head;
+    const TY* __restrict__ py = static_cast<const TY*>(fa.p[1]) + head;
+    const TZ* __restrict__ pz = static_cast<const TZ*>(fa.p[2]) + head;
+    const TW* __restrict__ pw = static_cast<const TW*>(fa.p[3]) + head;
     // launch-uniform operand configuration, resolved once per wave
     const bool ld_x = !fa.is_sc[0], ld_y = !fa.is_sc[1] && fa.alias[1] == 1, ld_z = !fa.is_sc[2] && fa.alias[2] == 2,
                ld_w = has_w && !fa.is_sc[3] && fa.alias[3] == 3;
@@ -92,10 +92,10 @@ __global__ __launch_bounds__(kBlock) void k_fused_mixed(FusedArgs fa, double* __
     for (int j = 0; j < kFusedU; ++j) {
         const size_t pr = base + size_t(j) * kBlock;
         if (full || pr < npairs) {
-            if (ld_x) x[j] = nt_load(px + pr);
-            if (ld_y) y[j] = nt_load(py + pr);
-            if (ld_z) z[j] = nt_load(pz + pr);
-            if (ld_w) w[j] = nt_load(pw + pr);
+            if (ld_x) x[j] = load_cells<true, TX, 2>(px + 2 * pr);
+            if (ld_y) y[j] = load_cells<true, TY, 2>(py + 2 * pr);
+            if (ld_z) z[j] = load_cells<true, TZ, 2>(pz + 2 * pr);
+            if (ld_w) w[j] = load_cells<true, TW, 2>(pw + 2 * pr);
         }
     }
 #pragma unroll
@@ -112,11 +112,11 @@ __global__ __launch_bounds__(kBlock) void k_fused_mixed(FusedArgs fa, double* __
                 ww = same_or<TW, TY>(ww, yy, fa.alias[3] == 1);
                 ww = same_or<TW, TZ>(ww, zz, fa.alias[3] == 2);
             }
-            const D2 vx = fa.is_sc[0] ? D2{fa.sc[0], fa.sc[0]} : D2{to_f64(x[j].x), to_f64(x[j].y)};
-            const D2 vy = fa.is_sc[1] ? D2{fa.sc[1], fa.sc[1]} : D2{to_f64(yy.x), to_f64(yy.y)};
-            const D2 vz = fa.is_sc[2] ? D2{fa.sc[2], fa.sc[2]} : D2{to_f64(zz.x), to_f64(zz.y)};
+            const D2 vx = fa.is_sc[0] ? D2{fa.sc[0], fa.sc[0]} : D2{to_f64(x[j][0]), to_f64(x[j][1])};
+            const D2 vy = fa.is_sc[1] ? D2{fa.sc[1], fa.sc[1]} : D2{to_f64(yy[0]), to_f64(yy[1])};
+            const D2 vz = fa.is_sc[2] ? D2{fa.sc[2], fa.sc[2]} : D2{to_f64(zz[0]), to_f64(zz[1])};
             D2 vw = vz;
-            if constexpr (has_w) vw = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : D2{to_f64(ww.x), to_f64(ww.y)};
+            if constexpr (has_w) vw = fa.is_sc[3] ? D2{fa.sc[3], fa.sc[3]} : D2{to_f64(ww[0]), to_f64(ww[1])};
             D2 o;
             if (small_ints) {  // launch-uniform
                 if constexpr (kSmallShape) {
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_mixed(FusedArgs fa, double* __
         const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;
         const size_t i = threadIdx.x == 0 ? 0 : n - 1;
         if (do_it)
-            out[i] = fused_cell_t<O1, O2, O3>(operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
-                                              has_w ? operand_cell(fa, 3, i) : 0.0);
+            st_cell(fused_cell_t<O1, O2, O3>(operand_cell(fa, 0, i), operand_cell(fa, 1, i), operand_cell(fa, 2, i),
+                                             has_w ? operand_cell(fa, 3, i) : 0.0), out + i);
     }
     fused_mask_phase(fa, out_mask, n);
 }

@@ -62,16 +62,22 @@ struct max_of { static constexpr int value = A > B ? A : B; };
 template <typename S, typename D>
 struct ConvertFn {
     static constexpr int CPL = 16 / max_of<sizeof(S), sizeof(D)>::value;
-    using SV = vec<S, CPL>;
     using DV = vec<D, CPL>;
-    using In = SV;
+    using In = cells<S, CPL>;  // 1-byte sources travel as words: their loads keep `nt` (ec_device.hpp)
     const S* __restrict__ src;
     D* __restrict__ dst;
-    __device__ __forceinline__ In load(size_t g) const { return nt_load(reinterpret_cast<const SV*>(src) + g); }
+    __device__ __forceinline__ In load(size_t g) const { return load_cells<true, S, CPL>(src + g * CPL); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
-        nt_store(__builtin_convertvector(x, DV), reinterpret_cast<DV*>(dst) + g);
+        if constexpr (sizeof(S) == 1) {
+            DV o;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) o[k] = static_cast<D>(x[k]);
+            nt_store(o, reinterpret_cast<DV*>(dst) + g);
+        } else {
+            nt_store(__builtin_convertvector(x.v, DV), reinterpret_cast<DV*>(dst) + g);
+        }
     }
-    __device__ __forceinline__ void cell(size_t i) const { dst[i] = static_cast<D>(src[i]); }
+    __device__ __forceinline__ void cell(size_t i) const { st_cell(static_cast<D>(ld_cell(src + i)), dst + i); }
 };
 
 // ---- neg: impl Neg for CellValue (src/value.rs:224-240)
@@ -101,19 +107,18 @@ template <typename T>
 struct NegFn {
     using O = typename NegOut<T>::type;
     static constexpr int CPL = 16 / max_of<sizeof(T), sizeof(O)>::value;
-    using SV = vec<T, CPL>;
     using DV = vec<O, CPL>;
-    using In = SV;
+    using In = cells<T, CPL>;
     const T* __restrict__ src;
     O* __restrict__ dst;
-    __device__ __forceinline__ In load(size_t g) const { return nt_load(reinterpret_cast<const SV*>(src) + g); }
+    __device__ __forceinline__ In load(size_t g) const { return load_cells<true, T, CPL>(src + g * CPL); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         DV o;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) o[k] = neg_cell<T>(x[k]);
         nt_store(o, reinterpret_cast<DV*>(dst) + g);
     }
-    __device__ __forceinline__ void cell(size_t i) const { dst[i] = neg_cell<T>(src[i]); }
+    __device__ __forceinline__ void cell(size_t i) const { st_cell(neg_cell<T>(ld_cell(src + i)), dst + i); }
 };
 
 // ---- fill: BufferOps::fill (src/buffer.rs:79-88). W = cell width in bytes.
@@ -131,7 +136,7 @@ struct FillFn {
         for (int k = 0; k < CPL; ++k) o[k] = value;
         nt_store(o, reinterpret_cast<DV*>(dst) + g);
     }
-    __device__ __forceinline__ void cell(size_t i) const { dst[i] = value; }
+    __device__ __forceinline__ void cell(size_t i) const { st_cell(value, dst + i); }
 };
 
 // ---- mask_from_nodata: from_vec_with_nodata (src/masked/masked_buffer.rs:62-71);
@@ -140,20 +145,19 @@ struct FillFn {
 template <typename W>
 struct MaskFromNodataFn {
     static constexpr int CPL = 16 / sizeof(W);
-    using SV = vec<W, CPL>;
     using MV = vec<uint8_t, CPL>;
-    using In = SV;
+    using In = cells<W, CPL>;
     const W* __restrict__ src;
     uint8_t* __restrict__ mask;
     W nd;
-    __device__ __forceinline__ In load(size_t g) const { return nt_load(reinterpret_cast<const SV*>(src) + g); }
+    __device__ __forceinline__ In load(size_t g) const { return load_cells<true, W, CPL>(src + g * CPL); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         MV m;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) m[k] = x[k] != nd;
         nt_store(m, reinterpret_cast<MV*>(mask) + g);
     }
-    __device__ __forceinline__ void cell(size_t i) const { mask[i] = src[i] != nd; }
+    __device__ __forceinline__ void cell(size_t i) const { st_cell<uint8_t>(ld_cell(src + i) != nd, mask + i); }
 };
 
 // ---- mask_select: to_vec_with_nodata (src/masked/masked_buffer.rs:143-148)
@@ -161,15 +165,13 @@ template <typename W>
 struct MaskSelectFn {
     static constexpr int CPL = 16 / sizeof(W);
     using SV = vec<W, CPL>;
-    using MV = vec<uint8_t, CPL>;
-    struct In { SV x; MV m; };
+    struct In { cells<W, CPL> x; cells<uint8_t, CPL> m; };  // the mask bytes as words (ec_device.hpp)
     const W* __restrict__ src;
     const uint8_t* __restrict__ mask;
     W* __restrict__ dst;
     W nd;
     __device__ __forceinline__ In load(size_t g) const {
-        return In{nt_load(reinterpret_cast<const SV*>(src) + g),
-                  nt_load(reinterpret_cast<const MV*>(mask) + g)};
+        return In{load_cells<true, W, CPL>(src + g * CPL), load_cells<true, uint8_t, CPL>(mask + g * CPL)};
     }
     __device__ __forceinline__ void store(size_t g, const In& in) const {
         SV o;
@@ -177,7 +179,10 @@ struct MaskSelectFn {
         for (int k = 0; k < CPL; ++k) o[k] = in.m[k] ? in.x[k] : nd;
         nt_store(o, reinterpret_cast<SV*>(dst) + g);
     }
-    __device__ __forceinline__ void cell(size_t i) const { dst[i] = mask[i] ? src[i] : nd; }
+    __device__ __forceinline__ void cell(size_t i) const {
+        const W v = ld_cell(src + i);  // unconditional: a load inside the select's arm comes out without `nt`
+        st_cell<W>(ld_cell(mask + i) ? v : nd, dst + i);
+    }
 };
 
 // ---- Mask BitAnd / BitOr / Not (src/masked/mask.rs:103-163): bytes are 0/1.
@@ -197,7 +202,10 @@ struct MaskBin {
     __device__ __forceinline__ void store(size_t g, const In& in) const {
         nt_store(KIND == 0 ? (in.a & in.b) : (in.a | in.b), reinterpret_cast<u32x4*>(out) + g);
     }
-    __device__ __forceinline__ void cell(size_t i) const { out[i] = KIND == 0 ? (l[i] & r[i]) : (l[i] | r[i]); }
+    __device__ __forceinline__ void cell(size_t i) const {
+        const uint8_t a = ld_cell(l + i), b = ld_cell(r + i);
+        st_cell<uint8_t>(KIND == 0 ? (a & b) : (a | b), out + i);
+    }
 };
 
 struct MaskNot {
@@ -209,7 +217,7 @@ struct MaskNot {
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         nt_store(x ^ 0x01010101u, reinterpret_cast<u32x4*>(out) + g);
     }
-    __device__ __forceinline__ void cell(size_t i) const { out[i] = m[i] ^ 1; }
+    __device__ __forceinline__ void cell(size_t i) const { st_cell<uint8_t>(ld_cell(m + i) ^ 1, out + i); }
 };
 
 // ---- synthetic inputs for bench/tests: counter-based, no stored vectors.
@@ -233,7 +241,7 @@ struct SynthFn {
         for (int k = 0; k < CPL; ++k) o[k] = gen(g * CPL + k);
         nt_store(o, reinterpret_cast<DV*>(dst) + g);
     }
-    __device__ __forceinline__ void cell(size_t i) const { dst[i] = gen(i); }
+    __device__ __forceinline__ void cell(size_t i) const { st_cell(gen(i), dst + i); }
 };
 
 struct SynthMaskFn {
@@ -251,7 +259,7 @@ struct SynthMaskFn {
         for (int k = 0; k < 16; ++k) o[k] = gen(g * 16 + k);
         nt_store(o, reinterpret_cast<DV*>(dst) + g);
     }
-    __device__ __forceinline__ void cell(size_t i) const { dst[i] = gen(i); }
+    __device__ __forceinline__ void cell(size_t i) const { st_cell(gen(i), dst + i); }
 };
 
 }  // namespace ecd

@@ -148,9 +148,9 @@ __global__ __launch_bounds__(BLOCK) void k_min_max_partials(const T* __restrict_
     n -= head;
     using A = typename AccT<T>::type;
     constexpr int CPL = 16 / sizeof(T);
-    using TV = vec<T, CPL>;
+    using TV = cells<T, CPL>;        // 1-byte cells and the mask bytes travel as words: their loads keep `nt` (ec_device.hpp)
     using AV = vec<A, CPL>;
-    using MV = vec<uint8_t, CPL>;
+    using MV = cells<uint8_t, CPL>;
     constexpr bool BYTES = sizeof(T) == 1;
     const A hi0 = acc_key<T>(Limits<T>::hi), lo0 = acc_key<T>(Limits<T>::lo);
     AV vmin, vmax;
@@ -162,14 +162,10 @@ __global__ __launch_bounds__(BLOCK) void k_min_max_partials(const T* __restrict_
     const size_t ngroups = n / CPL;
     constexpr size_t TILE = size_t(BLOCK) * U;
     const size_t ntiles = (ngroups + TILE - 1) / TILE;
-    const TV* __restrict__ pv = reinterpret_cast<const TV*>(p);
-    const MV* __restrict__ mv = reinterpret_cast<const MV*>(mask);
-
     auto fold = [&](const TV& x, const MV& m) {
         if constexpr (BYTES) {
-            const u32x4 xw = __builtin_bit_cast(u32x4, x), mw = __builtin_bit_cast(u32x4, m);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bf.template fold<MASKED>(xw[k], mw[k]);
+            for (int k = 0; k < 4; ++k) bf.template fold<MASKED>(x.v[k], m.v[k]);
         } else {
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
@@ -192,8 +188,8 @@ __global__ __launch_bounds__(BLOCK) void k_min_max_partials(const T* __restrict_
             MV m[U] = {};
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                x[j] = nt_load(pv + base + size_t(j) * BLOCK);
-                if constexpr (MASKED) m[j] = nt_load(mv + base + size_t(j) * BLOCK);
+                x[j] = load_cells<true, T, CPL>(p + (base + size_t(j) * BLOCK) * CPL);
+                if constexpr (MASKED) m[j] = load_cells<true, uint8_t, CPL>(mask + (base + size_t(j) * BLOCK) * CPL);
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) fold(x[j], m[j]);
@@ -203,8 +199,8 @@ __global__ __launch_bounds__(BLOCK) void k_min_max_partials(const T* __restrict_
                 const size_t g = base + size_t(j) * BLOCK;
                 if (g < ngroups) {
                     MV m = {};
-                    if constexpr (MASKED) m = plain_load(mv + g);
-                    fold(plain_load(pv + g), m);
+                    if constexpr (MASKED) m = load_cells<true, uint8_t, CPL>(mask + g * CPL);
+                    fold(load_cells<true, T, CPL>(p + g * CPL), m);
                 }
             }
         }
@@ -223,8 +219,8 @@ __global__ __launch_bounds__(BLOCK) void k_min_max_partials(const T* __restrict_
     }
     if (blockIdx.x == 0) {
         auto fold_cell = [&](ptrdiff_t i) {
-            if (MASKED && !mask[i]) return;
-            A key = acc_key<T>(p[i]);
+            if (MASKED && !ld_cell(mask + i)) return;
+            A key = acc_key<T>(ld_cell(p + i));
             amin = key < amin ? key : amin;
             amax = key > amax ? key : amax;
         };
@@ -342,27 +338,25 @@ __global__ __launch_bounds__(kRBlock) void k_first_diff_partials(const W* __rest
                                                                 uint64_t* __restrict__ partials, bool aligned,
                                                                 unsigned head) {
     constexpr int CPL = 16 / sizeof(W);
-    using WV = vec<W, CPL>;
+    using WV = cells<W, CPL>;
     uint64_t first = ~0ull;
     if (aligned) {
         // `head` leading cells are compared singly by workgroup 0 (see k_min_max_partials); indices stay absolute
         if (blockIdx.x == 0)
             for (unsigned h = threadIdx.x; h < head; h += kRBlock)
-                if (l[h] != r[h]) first = h < first ? h : first;
+                if (ld_cell(l + h) != ld_cell(r + h)) first = h < first ? h : first;
         l += head;
         r += head;
         n -= head;
         const size_t ngroups = n / CPL;
         constexpr size_t TILE = size_t(kRBlock) * U;
         const size_t ntiles = (ngroups + TILE - 1) / TILE;
-        const WV* __restrict__ lv = reinterpret_cast<const WV*>(l);
-        const WV* __restrict__ rv = reinterpret_cast<const WV*>(r);
         for (size_t tile = blockIdx.x; tile < ntiles && first == ~0ull; tile += gridDim.x) {
             const size_t base = tile * TILE + threadIdx.x;
             auto compare = [&](size_t g, const WV& a, const WV& b) {
                 // the 16 bytes as four words first: equal groups (the common case, and all of a scan that ends in
                 // "equal") cost 4 xor + 3 or instead of one compare per cell — 16 of them for 1-byte cells
-                const u32x4 d = __builtin_bit_cast(u32x4, a) ^ __builtin_bit_cast(u32x4, b);
+                const u32x4 d = __builtin_bit_cast(u32x4, a.v) ^ __builtin_bit_cast(u32x4, b.v);
                 if ((d.x | d.y | d.z | d.w) == 0) return;
 #pragma unroll
                 for (int k = CPL - 1; k >= 0; --k)
@@ -372,8 +366,8 @@ __global__ __launch_bounds__(kRBlock) void k_first_diff_partials(const W* __rest
                 WV a[U], b[U];
 #pragma unroll
                 for (int j = 0; j < U; ++j) {
-                    a[j] = nt_load(lv + base + size_t(j) * kRBlock);
-                    b[j] = nt_load(rv + base + size_t(j) * kRBlock);
+                    a[j] = load_cells<true, W, CPL>(l + (base + size_t(j) * kRBlock) * CPL);
+                    b[j] = load_cells<true, W, CPL>(r + (base + size_t(j) * kRBlock) * CPL);
                 }
 #pragma unroll
                 for (int j = 0; j < U; ++j) compare(base + size_t(j) * kRBlock, a[j], b[j]);
@@ -381,17 +375,17 @@ __global__ __launch_bounds__(kRBlock) void k_first_diff_partials(const W* __rest
 #pragma unroll
                 for (int j = 0; j < U; ++j) {
                     const size_t g = base + size_t(j) * kRBlock;
-                    if (g < ngroups) compare(g, nt_load(lv + g), nt_load(rv + g));
+                    if (g < ngroups) compare(g, load_cells<true, W, CPL>(l + g * CPL), load_cells<true, W, CPL>(r + g * CPL));
                 }
             }
         }
         if (blockIdx.x == 0)
             for (size_t i = ngroups * CPL + threadIdx.x; i < n; i += kRBlock)
-                if (l[i] != r[i]) first = head + i < first ? head + i : first;
+                if (ld_cell(l + i) != ld_cell(r + i)) first = head + i < first ? head + i : first;
     } else {
         const size_t stride = size_t(gridDim.x) * kRBlock;
         for (size_t i = size_t(blockIdx.x) * kRBlock + threadIdx.x; i < n && first == ~0ull; i += stride)
-            if (l[i] != r[i]) first = i;
+            if (ld_cell(l + i) != ld_cell(r + i)) first = i;
     }
     first = wave_min_u64(first);
     __shared__ uint64_t s_first[kRWaves];
@@ -442,7 +436,7 @@ __global__ __launch_bounds__(kRBlock) void k_mask_count_partials(const uint8_t* 
     uint64_t cnt = 0;
     if (aligned) {
         if (blockIdx.x == 0)  // peeled leading cells (see k_min_max_partials)
-            for (unsigned h = threadIdx.x; h < head; h += kRBlock) cnt += m[h] & 1;
+            for (unsigned h = threadIdx.x; h < head; h += kRBlock) cnt += ld_cell(m + h) & 1;
         m += head;
         n -= head;
         const size_t ngroups = n / 16;
@@ -473,10 +467,10 @@ __global__ __launch_bounds__(kRBlock) void k_mask_count_partials(const uint8_t* 
         }
         cnt += c32;
         if (blockIdx.x == 0)
-            for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kRBlock) cnt += m[i] & 1;
+            for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kRBlock) cnt += ld_cell(m + i) & 1;
     } else {
         const size_t stride = size_t(gridDim.x) * kRBlock;
-        for (size_t i = size_t(blockIdx.x) * kRBlock + threadIdx.x; i < n; i += stride) cnt += m[i] & 1;
+        for (size_t i = size_t(blockIdx.x) * kRBlock + threadIdx.x; i < n; i += stride) cnt += ld_cell(m + i) & 1;
     }
     cnt = wave_sum_u64(cnt);
     __shared__ uint64_t s_cnt[kRWaves];

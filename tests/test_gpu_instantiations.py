@@ -120,9 +120,8 @@ def test_fused_every_op_triple(ec, pool, ct):
                 assert_f64_bits_equal(g, eo, nan_by_class_where=loose)
 
 
-MIXED_PAIRS = [(eco.U16, eco.F32), (eco.F32, eco.U16), (eco.U8, eco.U16), (eco.U16, eco.U8),
-               (eco.I16, eco.F32), (eco.F32, eco.I16), (eco.F32, eco.F64), (eco.F64, eco.F32),
-               (eco.U8, eco.F32), (eco.F32, eco.U8), (eco.U16, eco.I16), (eco.I16, eco.U16)]
+# every ordered pair of distinct cell types (rounds 1-2 had one-pass kernels for 12 of these 90)
+MIXED_PAIRS = [(a, b) for a in range(NT) for b in range(NT) if a != b]
 
 
 def _pool_allocs(ec):
@@ -133,9 +132,9 @@ def _pool_allocs(ec):
 
 @pytest.mark.parametrize("pair", MIXED_PAIRS, ids=lambda p: f"{eco.CT_NAMES[p[0]]}-{eco.CT_NAMES[p[1]]}")
 def test_fused_mixed_every_instantiation(ec, pool, pair):
-    """All 28 x 4 k_fused_mixed<A,B,pattern,o1,o2,o3> kernels of each ordered type pair (A B A B with every op triple;
-    A A B, A B A, A B B with every op pair): against the oracle's chain (strict NaN rule), against the eager HIP
-    chain, against the convert-then-fuse path — and the one-pass path must not allocate."""
+    """Every ordered pair of distinct cell types through the one-pass kernel (k_fused_any, ec_fused_any.hpp): A B A B with
+    every op triple; A A B, A B A, A B B with every op pair: against the oracle's chain (strict NaN rule), against the
+    eager HIP chain, against the convert-then-fuse path — and the one-pass path must not allocate."""
     host, dev, _, _ = pool
     A, B = pair
     L = ec.lib()
@@ -251,6 +250,123 @@ def test_map_kernels_every_instantiation(ec, pool, map_u, vector, off):
     finally:
         L.ec_tune_set(b"map_u", 2)
         L.ec_tune_set(b"unaligned_vector", 1)
+
+
+_BY_WIDTH = {1: [eco.U8, eco.I8], 2: [eco.U16, eco.I16], 4: [eco.U32, eco.I32, eco.F32], 8: [eco.U64, eco.I64, eco.F64]}
+_CLASSES = (0, 1, 2, 4, 8)
+_SCALARS = (2.5, 3, -0.75, 7)
+
+
+def _class_case(ec, pool, classes, nops, tick):
+    """Operands whose load classes are `classes`: a class-c slot is a buffer of a c-byte cell type (kinds rotate with
+    `tick`) at its own offset; a class-0 slot is a scalar, or — when an earlier slot is a buffer — every other time the
+    same buffer as that slot.  Returns (device operands, host operands as the oracle sees them)."""
+    host, dev, _, _ = pool
+    ops, hs = [], []
+    for k in range(nops):
+        c = classes[k]
+        if c:
+            ct = _BY_WIDTH[c][(tick + k) % len(_BY_WIDTH[c])]
+            ops.append(dev[ct].shard(k, N))
+            hs.append(host[ct][k:k + N])
+        else:
+            earlier = [j for j in range(k) if not np.isscalar(ops[j])]
+            if earlier and (tick + k) % 2 == 0:
+                j = earlier[(tick // 2) % len(earlier)]
+                ops.append(ops[j])
+                hs.append(hs[j])
+            else:
+                sc = _SCALARS[(tick + k) % len(_SCALARS)]
+                ops.append(sc)
+                hs.append(np.full(N, float(sc)))  # a scalar operand is widened to f64 once, on the host (ec_fused.hip)
+    return ops, hs
+
+
+@pytest.mark.parametrize("cx", _CLASSES)
+def test_fused_any_every_class_kernel(ec, pool, cx):
+    """All 625 k_fused_any<CX,CY,CZ,CW> kernels (624 reachable: at least one operand is a buffer), four-operand chains
+    for every class quadruple and three-operand chains for every triple, cell kinds, aliases, scalars and op triples
+    rotating: against the oracle's chain under the single-op NaN rule; nothing is allocated."""
+    L = ec.lib()
+    L.ec_tune_set(b"fused_mixed", 2)  # same-type operand sets go through k_fused_any too
+    try:
+        tick = 0
+        for cy in _CLASSES:
+            for cz in _CLASSES:
+                for cw in _CLASSES:
+                    for nops in ((4, 3) if cw == 0 else (4,)):
+                        tick += 1
+                        classes = (cx, cy, cz, cw)
+                        if not any(classes[:nops]):
+                            continue  # all scalars: the ABI refuses it (checked in test_abi_host.py)
+                        ops, hs = _class_case(ec, pool, classes, nops, tick)
+                        if all(np.isscalar(o) for o in ops):
+                            continue
+                        o1, o2, o3 = OPS[tick % 4], OPS[(tick // 4) % 4], OPS[(tick // 16) % 4]
+                        before = _pool_allocs(ec)
+                        if nops == 4:
+                            got = ec.fused.expr(ops[0], o1, ops[1], o2, ops[2], o3, ops[3])
+                            eo, loose = _oracle_chain(o1, hs[0], hs[1], o2, hs[2], o3, hs[3])
+                        else:
+                            got = ec.fused.expr(ops[0], o1, ops[1], o2, ops[2])
+                            eo, loose = _oracle_chain(o1, hs[0], hs[1], o2, hs[2])
+                        assert _pool_allocs(ec) == before + 1, "one allocation: the result buffer"  # expr() allocates `out` only
+                        try:
+                            assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+                        except AssertionError as e:
+                            raise AssertionError(f"classes {classes} nops {nops} ops {(o1, o2, o3)}: {e}") from None
+    finally:
+        L.ec_tune_set(b"fused_mixed", 1)
+
+
+@pytest.mark.parametrize("ct", range(NT))
+def test_fused_any_equals_the_specialised_kernels(ec, pool, ct):
+    """Same-type chains run k_fused_same by default; forced through k_fused_any (fused_mixed = 2) every op triple gives
+    the same bits — including the NDVI shape on ≤16-bit cells, which both evaluate with the 6-instruction divide."""
+    host, dev, _, _ = pool
+    L = ec.lib()
+    x, y, z = dev[ct].shard(0, N), dev[ct].shard(4, N), dev[ct].shard(2, N)
+    for o1 in OPS:
+        for o2 in OPS:
+            for o3 in OPS + [ec.fused.OP_NONE]:
+                args = (x, o1, y, o2, x, o3, y) if o3 != ec.fused.OP_NONE else (x, o1, y, o2, z)
+                try:
+                    L.ec_tune_set(b"fused_mixed", 1)
+                    a = ec.fused.expr(*args).to_numpy()
+                    L.ec_tune_set(b"fused_mixed", 2)
+                    b = ec.fused.expr(*args).to_numpy()
+                finally:
+                    L.ec_tune_set(b"fused_mixed", 1)
+                assert np.array_equal(bits_of(a), bits_of(b)), (ct, o1, o2, o3)
+
+
+def test_fused_three_and_four_cell_types_with_masks(ec, pool):
+    """Chains over three and four cell types (rounds 1-2: convert-then-fuse) — masked operands, odd windows, ragged
+    lengths — against the oracle's chain and mask AND; no pooled temporaries."""
+    host, dev, m, dm = pool
+    quads = [(eco.U8, eco.U16, eco.F32, eco.F64), (eco.I64, eco.U8, eco.I16, eco.F32), (eco.F64, eco.U64, eco.I8, eco.U32),
+             (eco.U16, eco.F32, eco.F64, eco.F64), (eco.I32, eco.I32, eco.U8, eco.I64)]
+    for qi, q in enumerate(quads):
+        for n, off in ((N, 0), (1, 0), (2, 1), (515, 1), (2049, 3)):
+            bufs = [dev[t].shard(off + k, n) for k, t in enumerate(q)]
+            hs = [host[t][off + k:off + k + n] for k, t in enumerate(q)]
+            masks = [dm[k % 2].shard(off + k, n) for k in range(4)]
+            hm = [m[k % 2][off + k:off + k + n] for k in range(4)]
+            o1, o2, o3 = OPS[qi % 4], OPS[(qi + 3) % 4], OPS[(qi + 1) % 4]
+            before = _pool_allocs(ec)
+            got = ec.fused.expr(bufs[0], o1, bufs[1], o2, bufs[2], o3, bufs[3])
+            assert _pool_allocs(ec) == before + 1  # the result buffer
+            eo, loose = _oracle_chain(o1, hs[0], hs[1], o2, hs[2], o3, hs[3])
+            assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+            mb = [ec.MaskedCellBuffer(b, k) for b, k in zip(bufs, masks)]
+            gm = ec.fused.expr(mb[0], o1, mb[1], o2, mb[2])                      # three operands, three masks
+            eo3, loose3 = _oracle_chain(o1, hs[0], hs[1], o2, hs[2])
+            assert_f64_bits_equal(gm.buffer().to_numpy(), eo3, nan_by_class_where=loose3)
+            assert np.array_equal(gm.mask().to_numpy(), hm[0] & hm[1] & hm[2])
+            gm = ec.fused.expr(mb[0], o1, mb[1], o2, mb[2], o3, 2.5)             # a scalar in the last slot carries no mask
+            eo4, loose4 = _oracle_chain(o1, hs[0], hs[1], o2, hs[2], o3, np.full(n, 2.5))
+            assert_f64_bits_equal(gm.buffer().to_numpy(), eo4, nan_by_class_where=loose4)
+            assert np.array_equal(gm.mask().to_numpy(), hm[0] & hm[1] & hm[2])
 
 
 SMALL = {  # cell type -> (lowest, highest) cell value
