@@ -51,7 +51,10 @@ def parse():
     ap.add_argument("--side", type=int, default=16384, help="raster is side x side cells")
     ap.add_argument("--rows", type=int, default=None,
                     help="raster rows (default: side); e.g. --rows 2048 times on one GPU the row-block one rank owns at N=8")
-    ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax", "ndvi"])
+    ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax", "ndvi", "binop"])
+    ap.add_argument("--lt", default="u16", help="--workload binop: lhs cell type (u8 u16 u32 u64 i8 i16 i32 i64 f32 f64)")
+    ap.add_argument("--rt", default="u16", help="--workload binop: rhs cell type")
+    ap.add_argument("--op", default="add", choices=["add", "sub", "mul", "div"], help="--workload binop: operator")
     ap.add_argument("--fused", action="store_true", help="masked_chain / ndvi: the single-pass fused kernel instead of the eager chain")
     ap.add_argument("--mixed", action="store_true", help="ndvi: red band as f32 (mixed operand types -> the generic fused kernel)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -169,17 +172,18 @@ def e2e_pipelined(torch, ec, L, a, b, out, n: int, chunk: int = 1 << 25) -> dict
             "what": f"pinned host buffers, {nchunks} chunks of 2^25 cells, H2D / divide / D2H on three streams, double-buffered"}
 
 
-def recorded_traffic(cells_per_launch: int):
-    """(HBM bytes per launch, where the figure comes from) of the dominant kernel.  PMC counters cannot be read
+def recorded_traffic(key: str, cells_per_launch: int):
+    """(HBM bytes per step, where the figure comes from) of the workload's kernels.  PMC counters cannot be read
     from inside this process, so this is a RECORDED figure, not a live one: the committed rocprofv3 --pmc passes
-    over this same command (profiles/traffic.json: kernel signature, commit and method; corrected as
-    MI355X_MICROARCH.md §HBM prescribes).  (None, None) when no record matches the launch size."""
+    over this same command (profiles/traffic.json: kernel signatures, commit and method; corrected as
+    MI355X_MICROARCH.md §HBM prescribes; tools/pmc_summary.py).  (None, None) when no record matches the workload
+    and launch size."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             rec = json.load(f)
-        e = rec.get("binop_div_u8_u16", {})
+        e = rec.get(key, {})
         if e.get("cells_per_launch") == cells_per_launch:
-            return e.get("hbm_bytes_per_launch"), f"recorded profiles/traffic.json @{e.get('commit', '?')} (round {e.get('round', '?')}), not measured in this run"
+            return e.get("hbm_bytes_per_launch"), f"recorded profiles/traffic.json[{key}] @{e.get('commit', '?')} (round {e.get('round', '?')}), not measured in this run"
     except Exception:
         pass
     return None, None
@@ -218,9 +222,9 @@ class _StdoutToStderr:
 def self_launch(args) -> int:
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as fresh child
     processes (`python -m torch.distributed.run ... bench.py <same flags>`, one rank per GPU) and return their
-    exit code.  Runs before this process makes any GPU call — it only counts the devices, which does not
-    initialise the runtime — and never replaces itself: the ranks are children, rank 0's JSON line reaches
-    this process's stdout through the inherited descriptor."""
+    exit code.  This process only counts the devices (hipGetDeviceCount under torch.cuda.device_count()) and launches
+    no GPU work of its own; it never replaces itself — the ranks are fresh child processes with their own HIP runtime,
+    rank 0's JSON line reaches this process's stdout through the inherited descriptor."""
     import socket
     import subprocess
 
@@ -257,9 +261,22 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     ndev = max(1, torch.cuda.device_count())
-    # one rank per GPU; when a launcher masks the devices per rank (each rank sees only its own as device 0) use that one
-    dev = 0 if args.single_device else (local_rank if local_rank < ndev else local_rank % ndev)
+    # One rank per GPU, and only that: either this process sees every GPU of the node (dev = local_rank), or a launcher
+    # masks the devices per rank and each rank sees exactly its own as device 0, or --single-device says out loud that
+    # all ranks share device 0 (a rehearsal).  Anything else (8 ranks started on a 4-GPU box ...) would put several ranks
+    # on one GPU and still print an N-GPU line, so it is refused.
+    if args.single_device:
+        dev = 0
+    elif local_rank < ndev:
+        dev = local_rank
+    elif ndev == 1:
+        dev = 0  # per-rank device masking; rank 0 checks below that the ranks' devices are distinct
+    else:
+        sys.exit(f"bench.py: rank {rank} (local rank {local_rank}) has no GPU of its own: {ndev} HIP devices visible for "
+                 f"{world} ranks — start one rank per GPU (or --single-device for a rehearsal)")
     torch.cuda.set_device(dev)
+    props = torch.cuda.get_device_properties(dev)
+    dev_id = f"{props.name} uuid={getattr(props, 'uuid', '?')} pci={getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}"
     use_dist = world > 1 or os.environ.get("EC_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank rehearsal of the RCCL path
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -304,10 +321,25 @@ def main():
         chk(L.ec_synth_fill(ec.UInt8, a.mem.ptr, n, 0x5EED0001, off, 0.0, 255.0, stream))
         chk(L.ec_synth_fill(ec.UInt16, b.mem.ptr, n, 0x5EED0002, off, 1.0, 65535.0, stream))
         bytes_per_cell, kernel = 11, "k_binop_direct<u8,u16,Div>" if (args.variant or 0) == 0 else "k_binop_lds<u8,u16,Div>"
+        traffic_key = "binop_div_u8_u16" if (args.variant or 0) == 0 else "binop_div_u8_u16_lds"
         wl = f"{args.rows or side}x{side} u8/u16->f64 CellBuffer divide (BASELINE configs[1]" + (")" if not args.rows else f"; the row-block of 1/{max(1, side // args.rows)} shard)")
 
         def step():
             chk(L.ec_binop(ec.DIV, ec.UInt8, a.mem.ptr, ec.UInt16, b.mem.ptr, n, out.mem.ptr, stream))
+    elif args.workload == "binop":  # any pair of cell types through the same entry point (profiles/)
+        names = ["u8", "u16", "u32", "u64", "i8", "i16", "i32", "i64", "f32", "f64"]
+        lt, rt, op = names.index(args.lt), names.index(args.rt), ["add", "sub", "mul", "div"].index(args.op)
+        a, b = ec.CellBuffer.empty(n, lt), ec.CellBuffer.empty(n, rt)
+        out = ec.CellBuffer.empty(n, ec.Float64)
+        chk(L.ec_synth_fill(lt, a.mem.ptr, n, 0x5EED0021, off, 1.0, 100.0, stream))
+        chk(L.ec_synth_fill(rt, b.mem.ptr, n, 0x5EED0022, off, 1.0, 100.0, stream))
+        bytes_per_cell = ec.size_of(lt) + ec.size_of(rt) + 8
+        kernel = f"k_binop_direct<{args.lt},{args.rt},{args.op}>"
+        traffic_key = f"binop_{args.op}_{args.lt}_{args.rt}"
+        wl = f"{args.rows or side}x{side} {args.lt} {args.op} {args.rt} -> f64 CellBuffer operator"
+
+        def step():
+            chk(L.ec_binop(op, lt, a.mem.ptr, rt, b.mem.ptr, n, out.mem.ptr, stream))
     elif args.workload == "masked_chain":
         bufs = [ec.CellBuffer.empty(n, ec.Float32) for _ in range(3)]
         masks = [ec.Mask.empty(n) for _ in range(3)]
@@ -317,6 +349,7 @@ def main():
         t1, m1 = ec.CellBuffer.empty(n, ec.Float64), ec.Mask.empty(n)
         out, m2 = ec.CellBuffer.empty(n, ec.Float64), ec.Mask.empty(n)
         bytes_per_cell, kernel = 42, "k_masked_binop<f32,f32,Add> + k_masked_binop<f64,f32,Mul>"
+        traffic_key = "masked_chain"
         wl = f"{side}x{side} MaskedCellBuffer f32 (a+b)*c, 30% nodata (BASELINE configs[2], eager)"
         dt4 = (C.c_uint8 * 4)(ec.Float32, ec.Float32, ec.Float32, 0)
         p4 = (C.c_void_p * 4)(bufs[0].mem.ptr, bufs[1].mem.ptr, bufs[2].mem.ptr, None)
@@ -336,8 +369,9 @@ def main():
         chk(L.ec_synth_fill(ec.UInt16, nir.mem.ptr, n, 0x5EED0007, off, 5000.0, 40000.0, stream))
         chk(L.ec_synth_fill(red_t, red.mem.ptr, n, 0x5EED0008, off, 5000.0, 30000.0, stream))
         t1, t2, out = (ec.CellBuffer.empty(n, ec.Float64) for _ in range(3))
+        traffic_key = "ndvi" + ("_fused" if args.fused else "") + ("_mixed" if args.mixed else "")
         if args.fused:
-            bytes_per_cell, kernel = (14 if args.mixed else 12), "k_fused (nir-red)/(nir+red), one pass"
+            bytes_per_cell, kernel = (14 if args.mixed else 12), ("k_fused_any<2,4,0,0>" if args.mixed else "k_fused_any<2,2,0,0>") + " (nir-red)/(nir+red), one pass"
             dt4 = (C.c_uint8 * 4)(ec.UInt16, red_t, ec.UInt16, red_t)
             p4 = (C.c_void_p * 4)(nir.mem.ptr, red.mem.ptr, nir.mem.ptr, red.mem.ptr)
 
@@ -356,6 +390,7 @@ def main():
         chk(L.ec_synth_fill(ec.UInt16, a.mem.ptr, n, 0x5EED0006, off, 1.0, 65534.0, stream))
         keys = torch.empty(2, dtype=torch.int64, device="cuda")
         bytes_per_cell, kernel = 2, "k_min_max_partials<u16>"
+        traffic_key = "minmax"
         wl = f"{side}x{side} u16 min_max, row-sharded, all-reduce of 2 int64 keys (BASELINE configs[3] shape)"
         if side == 65536:
             wl += (f"; configs[3]'s whole 8.6 GB raster, {rows_total // world} rows per rank" +
@@ -368,7 +403,8 @@ def main():
 
     if args.workload == "masked_chain" and args.fused:
         step = step_fused
-        bytes_per_cell, kernel = 24, "k_fused (a+b)*c f32 + 3 masks, one pass"
+        traffic_key = "masked_chain_fused"
+        bytes_per_cell, kernel = 24, "k_fused_any<4,4,4,0> (a+b)*c f32 + 3 masks, one pass"
         wl = wl.replace("eager", "fused")
 
     # ---- clock ramp + warm-up, then EXACTLY `steps` timed steps between barrier+synchronize.
@@ -441,6 +477,13 @@ def main():
         per_rank = [g.cpu().tolist() for g in gathered]
     else:
         per_rank = [mine.tolist()]
+    if use_dist:
+        dev_ids = [None] * world
+        dist.all_gather_object(dev_ids, dev_id)
+    else:
+        dev_ids = [dev_id]
+    if rank == 0 and world > 1 and not args.single_device and len(set(dev_ids)) != world:
+        sys.exit(f"bench.py: the {world} ranks do not sit on {world} distinct GPUs: {dev_ids}")
     elapsed = max(r[0] for r in per_rank)          # MAX over ranks
     slowest = max(range(len(per_rank)), key=lambda i: per_rank[i][1])
     dev_ms = per_rank[slowest][1]
@@ -452,8 +495,8 @@ def main():
         launch_ms = dev_ms / args.steps
         n_slowest = int(per_rank[slowest][2])
         achieved = bytes_per_cell * n_slowest / (launch_ms * 1e-3) / 1e9  # the slowest GPU's launch: its bytes / its time
-        traffic, traffic_source = recorded_traffic(n_slowest) if (args.workload == "div_u8_u16" and world == 1) else (None, None)
-        per_gpu = [{"rank": i, "cells": int(r[2]), "launch_ms": r[1] / args.steps,
+        traffic, traffic_source = recorded_traffic(traffic_key, n_slowest) if world == 1 else (None, None)
+        per_gpu = [{"rank": i, "device": dev_ids[i], "cells": int(r[2]), "launch_ms": r[1] / args.steps,
                     "frac": bytes_per_cell * r[2] / (r[1] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS} for i, r in enumerate(per_rank)]
         res = {
             "metric": METRIC if args.workload == "div_u8_u16" else f"Gcells/s ({args.workload})",

@@ -48,6 +48,7 @@ static void load_rccl() {
     EC_SYM(comm_init_rank, "ncclCommInitRank");
     EC_SYM(comm_init_all, "ncclCommInitAll");
     EC_SYM(comm_destroy, "ncclCommDestroy");
+    EC_SYM(comm_abort, "ncclCommAbort");
     EC_SYM(group_start, "ncclGroupStart");
     EC_SYM(group_end, "ncclGroupEnd");
 #undef EC_SYM

@@ -15,6 +15,7 @@ struct Rccl {
     ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*comm_init_all)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*comm_abort)(ncclComm_t) = nullptr;  // optional: used only to unblock a poisoned shard group
     ncclResult_t (*group_start)() = nullptr;
     ncclResult_t (*group_end)() = nullptr;
 };

@@ -41,6 +41,8 @@ struct Tuning {
     std::atomic<int> unaligned_vector{1};  // 1 = vector kernels at any cell offset (gfx950 unaligned global access);
                                            // 0 = pointers that are not 16-byte aligned run the cell-wise kernels
     std::atomic<int> fused_mixed{1};       // 1 = one-pass typed-load kernels for fused chains over mixed cell types; 0 = convert, then fuse
+    std::atomic<int> inject_shard_failure{0};  // test hook: shard index + 1 whose NEXT fire-and-forget job of a shard group reports
+                                               // EC_ERR_HIP instead of launching (exercises the deferred-error path); 0 = off
     std::atomic<int64_t> pool_keep_mb{32768};  // release threshold of the library's stream-ordered pool (per device)
 };
 

@@ -7,12 +7,27 @@
 //   * a non-blocking stream with its reduction scratch,
 //   * a 32-byte device payload slot and a 32-byte pinned host slot,
 //   * an RCCL communicator of the n-device clique (ncclCommInitAll) unless EC_GROUP_HOST_COMBINE.
-// Element-wise entry points fan out and return; the reductions fan out, all-reduce their 16-byte payloads over
-// xGMI (each launch thread issues the ncclAllReduce of its own communicator — the one-thread-per-device use of
-// RCCL needs no group call), copy the payload back and wait.  Every wave of every kernel launched here finishes
-// on its own (no persistent kernels), so destroying a group only has to wait for its streams.
+//
+// Element-wise entry points are FIRE-AND-FORGET (round 3): the calling thread checks the arguments, copies the
+// per-shard pointers into one job per launch thread, posts the jobs and returns — it does not wait for the launch
+// threads to have issued.  A launch thread that has just run a job polls its queue for a few tens of microseconds
+// before it sleeps, so back-to-back sharded calls cost the caller a queue push per device and no futex wake
+// (profiles/r03/group_fanout.md).  A failure inside a posted job (a launch error) is recorded in the group and
+// returned by the next ec_shard_group_sync or reduction.  Rounds 1-2 blocked every call on a latch until all
+// threads had issued (EC_GROUP_BLOCKING_ISSUE keeps that form for comparison).
+//
+// The reductions are synchronous and run in phases, so that a shard that fails cannot leave the others waiting in a
+// collective: (0) every shard's arguments are checked on the calling thread, (1) every shard reduces locally to its
+// payload slot — all statuses are collected, (2) only if ALL are EC_OK does every launch thread enqueue the
+// ncclAllReduce of its own communicator (the one-thread-per-device use of RCCL needs no group call), (3) copy back and
+// wait.  If an enqueue of phase 2 fails on some shard after others have enqueued, the group is poisoned: its
+// communicators are aborted (ncclCommAbort) so that no stream waits for the missing rank, and every later call returns
+// EC_ERR_RCCL.  Every wave of every kernel launched here finishes on its own (no persistent kernels), so destroying a
+// group only has to wait for its streams.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -24,11 +39,15 @@
 #include <vector>
 
 #include "ec_collective.hpp"
+#include "ec_lattice.hpp"
 #include "ec_runtime.hpp"
 
 using namespace ecd;
 
 namespace {
+
+// How long a launch thread polls its queue after a job before it goes to sleep on the condition variable.
+constexpr auto kWorkerSpin = std::chrono::microseconds(60);
 
 struct Worker {
     int device = -1;
@@ -36,18 +55,29 @@ struct Worker {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::function<void()>> q;
+    std::atomic<int> pending{0};      // jobs in q (read by the polling worker without the lock)
+    std::atomic<bool> sleeping{false};
     bool stop = false;
 
     void run() {
         (void)ec_set_device(device);  // for the life of the thread
         for (;;) {
             std::function<void()> job;
+            if (pending.load(std::memory_order_acquire) == 0) {  // poll, then sleep
+                const auto until = std::chrono::steady_clock::now() + kWorkerSpin;
+                while (pending.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+            }
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || !q.empty(); });
-                if (q.empty()) return;  // stop requested and drained
+                if (q.empty()) {
+                    sleeping.store(true, std::memory_order_release);
+                    cv.wait(lk, [&] { return stop || !q.empty(); });
+                    sleeping.store(false, std::memory_order_release);
+                    if (q.empty()) return;  // stop requested and drained
+                }
                 job = std::move(q.front());
                 q.pop_front();
+                pending.fetch_sub(1, std::memory_order_acq_rel);
             }
             job();
         }
@@ -56,8 +86,11 @@ struct Worker {
         {
             std::lock_guard<std::mutex> lk(mu);
             q.push_back(std::move(job));
+            pending.fetch_add(1, std::memory_order_acq_rel);
         }
-        cv.notify_one();
+        // a polling worker sees `pending`; only a sleeping one needs the wake-up.  (The worker sets `sleeping` under
+        // `mu` after finding the queue empty, so a job pushed before that is found, one pushed after sees the flag.)
+        if (sleeping.load(std::memory_order_acquire)) cv.notify_one();
     }
 };
 
@@ -87,23 +120,54 @@ struct ec_shard_group {
     std::vector<int64_t*> payload_host;  // 4 words per shard, pinned
     std::vector<ncclComm_t> comms;       // empty with EC_GROUP_HOST_COMBINE
     std::vector<Worker*> workers;        // empty when n == 1: the caller's thread does the work
-    std::mutex call_mu;                  // one sharded call at a time per group (payload slots are per group)
+    std::mutex call_mu;                  // one sharded call is POSTED at a time per group (keeps every device's queue in
+                                         // call order); the synchronous calls hold it to their end (payload slots are per group)
+    std::mutex err_mu;                   // first failure of a fire-and-forget job, until a sync / reduction returns it
+    ec_status deferred = EC_OK;
+    std::string deferred_text;
+    std::atomic<bool> poisoned{false};   // a collective was left incomplete: communicators aborted, the group is unusable
+    std::atomic<int64_t> posted{0};      // fire-and-forget jobs posted / run (statistics for tools/group_bench.c)
 };
 
 namespace {
 
-// fn(i) on every shard's launch thread, concurrently; first failing status (and its message) wins.
-ec_status for_each_shard(ec_shard_group* g, const std::function<ec_status(int)>& fn) {
+using ShardFn = std::function<ec_status(int)>;
+
+void record_deferred(ec_shard_group* g, int i, ec_status st, const std::string& text) {
+    std::lock_guard<std::mutex> lk(g->err_mu);
+    if (g->deferred != EC_OK) return;  // first failure wins
+    g->deferred = st;
+    g->deferred_text = "shard " + std::to_string(i) + " (device " + std::to_string(g->devices[i]) + "): " + text;
+}
+
+ec_status take_deferred(ec_shard_group* g) {
+    std::lock_guard<std::mutex> lk(g->err_mu);
+    if (g->deferred == EC_OK) return EC_OK;
+    const ec_status st = g->deferred;
+    g->deferred = EC_OK;
+    return set_error_text(st, g->deferred_text + " (reported by a later call: the failing call had already returned)");
+}
+
+// fn(0) on the caller's thread with the group's device bound (groups of one shard have no launch threads)
+ec_status run_inline(ec_shard_group* g, const ShardFn& fn) {
+    int32_t before = -1;
+    const bool had = ec_get_device(&before) == EC_OK;
+    ec_status st = ec_set_device(g->devices[0]);
+    if (st == EC_OK) st = fn(0);
+    if (had && before != g->devices[0]) {
+        const std::string keep = last_error_text();
+        (void)ec_set_device(before);
+        if (st != EC_OK) set_error_text(st, keep);
+    }
+    return st;
+}
+
+// fn(i) on every shard's launch thread, concurrently; waits for all; every status is collected, the first failing one
+// (and its message) is returned.
+ec_status for_each_shard(ec_shard_group* g, const ShardFn& fn, std::vector<ec_status>* all = nullptr) {
     if (g->workers.empty()) {  // n == 1
-        int32_t before = -1;
-        const bool had = ec_get_device(&before) == EC_OK;
-        ec_status st = ec_set_device(g->devices[0]);
-        if (st == EC_OK) st = fn(0);
-        if (had && before != g->devices[0]) {
-            const std::string keep = last_error_text();
-            (void)ec_set_device(before);
-            if (st != EC_OK) set_error_text(st, keep);
-        }
+        const ec_status st = run_inline(g, fn);
+        if (all) all->assign(1, st);
         return st;
     }
     std::vector<ec_status> status(g->n, EC_OK);
@@ -117,28 +181,81 @@ ec_status for_each_shard(ec_shard_group* g, const std::function<ec_status(int)>&
         });
     }
     done.wait();
+    if (all) *all = status;
     for (int i = 0; i < g->n; ++i)
         if (status[i] != EC_OK) return set_error_text(status[i], "shard " + std::to_string(i) + " (device " + std::to_string(g->devices[i]) + "): " + text[i]);
     return EC_OK;
 }
 
-ec_status check_group(const ec_shard_group* g, const char* what) {
-    if (!g || g->n < 1) return set_error(EC_ERR_ARG, "%s: null shard group", what);
+// Fire-and-forget: fn owns copies of everything it needs.  Returns once the jobs are posted; failures are deferred.
+ec_status post_each_shard(ec_shard_group* g, ShardFn fn) {
+    if (g->flags & EC_GROUP_BLOCKING_ISSUE) return for_each_shard(g, fn);
+    if (g->workers.empty()) return run_inline(g, fn);  // one shard: issuing IS the call, nothing to hand over
+    auto shared = std::make_shared<ShardFn>(std::move(fn));
+    for (int i = 0; i < g->n; ++i) {
+        g->workers[i]->post([g, i, shared] {
+            int want = i + 1;  // test hook (ec_tune_set("inject_shard_failure", shard + 1)): this job fails instead of launching
+            const bool injected = tuning().inject_shard_failure.compare_exchange_strong(want, 0);
+            const ec_status st = injected ? set_error(EC_ERR_HIP, "injected failure (inject_shard_failure)") : (*shared)(i);
+            if (st != EC_OK) record_deferred(g, i, st, last_error_text());
+        });
+    }
+    g->posted.fetch_add(g->n, std::memory_order_relaxed);
     return EC_OK;
 }
 
-// After the per-shard payloads {a, b} are in payload_dev[i][0..1]: exchange, bring them to the host, wait.
-ec_status exchange(ec_shard_group* g, int i, bool is_keys) {
-    hipStream_t s = g->streams[i];
+ec_status check_group(const ec_shard_group* g, const char* what) {
+    if (!g || g->n < 1) return set_error(EC_ERR_ARG, "%s: null shard group", what);
+    if (g->poisoned.load(std::memory_order_acquire))
+        return set_error(EC_ERR_RCCL, "%s: the shard group is poisoned (a collective was left incomplete; destroy the group)", what);
+    return EC_OK;
+}
+
+// n[i] cells at p[i] for every shard: no null pointer where there are cells (checked on the calling thread, before
+// any fan-out: a shard that failed alone would otherwise leave the others inside a collective)
+ec_status check_shard_ptrs(const ec_shard_group* g, const char* what, const char* name, const void* const* p, const size_t* n) {
+    for (int i = 0; i < g->n; ++i)
+        if (n[i] > 0 && !p[i]) return set_error(EC_ERR_ARG, "%s: %s[%d] is null with n[%d] = %zu", what, name, i, i, n[i]);
+    return EC_OK;
+}
+
+template <typename P>
+std::vector<P> copy_n(const P* a, int n) { return std::vector<P>(a, a + n); }
+
+void poison(ec_shard_group* g) {
+    g->poisoned.store(true, std::memory_order_release);
+    const Rccl* R = rccl("ec_shard_group(poison)");
+    for (ncclComm_t c : g->comms)
+        if (c && R && R->comm_abort) (void)R->comm_abort(c);  // unblocks the ranks that did enqueue
+    g->comms.assign(g->comms.size(), nullptr);
+}
+
+// The exchange step of a reduction whose per-shard payloads {a, b} are in payload_dev[i][0..1] on EVERY shard
+// (phase 1 succeeded everywhere).  Phase 2: every launch thread enqueues its all-reduce; phase 3: copy back, wait.
+ec_status exchange(ec_shard_group* g, bool is_keys) {
     if (!g->comms.empty()) {
-        ec_status st = is_keys ? ec_allreduce_min_max_keys(g->comms[i], g->payload_dev[i], s)
-                               : ec_allreduce_counts(g->comms[i], reinterpret_cast<uint64_t*>(g->payload_dev[i]), s);
-        if (st != EC_OK) return st;
+        std::vector<ec_status> all;
+        ec_status st = for_each_shard(g, [&](int i) {
+            return is_keys ? ec_allreduce_min_max_keys(g->comms[i], g->payload_dev[i], g->streams[i])
+                           : ec_allreduce_counts(g->comms[i], reinterpret_cast<uint64_t*>(g->payload_dev[i]), g->streams[i]);
+        }, &all);
+        if (st != EC_OK) {
+            bool some_enqueued = false;
+            for (ec_status s : all) some_enqueued = some_enqueued || s == EC_OK;
+            if (some_enqueued && g->n > 1) {
+                const std::string keep = last_error_text();
+                poison(g);
+                return set_error_text(st, keep + " — other shards had enqueued the collective: group poisoned, communicators aborted");
+            }
+            return st;
+        }
     }
-    ec_status st = check_hip(hipMemcpyAsync(g->payload_host[i], g->payload_dev[i], 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s),
-                             "hipMemcpyAsync(payload)");
-    if (st != EC_OK) return st;
-    return check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+    return for_each_shard(g, [&](int i) {
+        ec_status st = check_hip(hipMemcpyAsync(g->payload_host[i], g->payload_dev[i], 2 * sizeof(int64_t), hipMemcpyDeviceToHost, g->streams[i]),
+                                 "hipMemcpyAsync(payload)");
+        if (st != EC_OK) return st;
+        return check_hip(hipStreamSynchronize(g->streams[i]), "hipStreamSynchronize");
+    });
 }
 
 }  // namespace
@@ -244,11 +361,26 @@ extern "C" ec_status ec_shard_group_foreach(ec_shard_group* g, ec_shard_fn fn, v
     return for_each_shard(g, [&](int i) { return fn(i, g->devices[i], g->streams[i], user); });
 }
 
+// Waits until every posted job has been issued and every shard's stream has drained; returns the first failure a
+// fire-and-forget call left behind (and clears it), else the streams' own status.
 extern "C" ec_status ec_shard_group_sync(ec_shard_group* g) {
-    ec_status st = check_group(g, "ec_shard_group_sync");
-    if (st != EC_OK) return st;
+    if (!g || g->n < 1) return set_error(EC_ERR_ARG, "ec_shard_group_sync: null shard group");
     std::lock_guard<std::mutex> lk(g->call_mu);
-    return for_each_shard(g, [&](int i) { return check_hip(hipStreamSynchronize(g->streams[i]), "hipStreamSynchronize"); });
+    const ec_status st = for_each_shard(g, [&](int i) { return check_hip(hipStreamSynchronize(g->streams[i]), "hipStreamSynchronize"); });
+    const std::string keep = last_error_text();
+    const ec_status deferred = take_deferred(g);
+    if (deferred != EC_OK) return deferred;
+    if (st != EC_OK) return set_error_text(st, keep);
+    return check_group(g, "ec_shard_group_sync");  // a poisoned group says so
+}
+
+extern "C" ec_status ec_shard_group_stat(const ec_shard_group* g, const char* key, int64_t* value) {
+    if (!g || !key || !value) return set_error(EC_ERR_ARG, "ec_shard_group_stat: null argument");
+    if (!std::strcmp(key, "jobs_posted")) *value = g->posted.load(std::memory_order_relaxed);
+    else if (!std::strcmp(key, "poisoned")) *value = g->poisoned.load(std::memory_order_acquire) ? 1 : 0;
+    else if (!std::strcmp(key, "blocking_issue")) *value = (g->flags & EC_GROUP_BLOCKING_ISSUE) ? 1 : 0;
+    else return set_error(EC_ERR_ARG, "ec_shard_group_stat: unknown key '%s'", key);
+    return EC_OK;
 }
 
 extern "C" ec_status ec_sharded_alloc(ec_shard_group* g, const size_t* bytes, void** dptrs) {
@@ -266,9 +398,9 @@ extern "C" ec_status ec_sharded_alloc(ec_shard_group* g, const size_t* bytes, vo
     return EC_OK;
 }
 
+// (queued behind the launches posted so far on each device; hipFree then waits for the device)
 extern "C" ec_status ec_sharded_free(ec_shard_group* g, void* const* dptrs) {
-    ec_status st = check_group(g, "ec_sharded_free");
-    if (st != EC_OK) return st;
+    if (!g || g->n < 1) return set_error(EC_ERR_ARG, "ec_sharded_free: null shard group");  // a poisoned group still frees
     if (!dptrs) return set_error(EC_ERR_ARG, "ec_sharded_free: null argument");
     std::lock_guard<std::mutex> lk(g->call_mu);
     return for_each_shard(g, [&](int i) { return ec_free(dptrs[i]); });
@@ -296,13 +428,21 @@ extern "C" ec_status ec_sharded_download(ec_shard_group* g, void* dst_host, cons
     });
 }
 
+// ---- element-wise: checked on the calling thread, posted, not waited for
 extern "C" ec_status ec_sharded_binop(ec_shard_group* g, ec_op op, ec_dtype lt, const void* const* l, ec_dtype rt,
                                       const void* const* r, const size_t* n, double* const* out) {
     ec_status st = check_group(g, "ec_sharded_binop");
     if (st != EC_OK) return st;
     if (!l || !r || !n || !out) return set_error(EC_ERR_ARG, "ec_sharded_binop: null argument");
+    if (op < EC_ADD || op > EC_DIV) return set_error(EC_ERR_ARG, "ec_sharded_binop: bad op");
+    if (!ecl::valid(lt) || !ecl::valid(rt)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_sharded_binop: bad dtype");
+    if ((st = check_shard_ptrs(g, "ec_sharded_binop", "l", l, n)) != EC_OK) return st;
+    if ((st = check_shard_ptrs(g, "ec_sharded_binop", "r", r, n)) != EC_OK) return st;
+    if ((st = check_shard_ptrs(g, "ec_sharded_binop", "out", reinterpret_cast<const void* const*>(out), n)) != EC_OK) return st;
     std::lock_guard<std::mutex> lk(g->call_mu);
-    return for_each_shard(g, [&](int i) { return ec_binop(op, lt, l[i], rt, r[i], n[i], out[i], g->streams[i]); });
+    return post_each_shard(g, [g, op, lt, rt, l = copy_n(l, g->n), r = copy_n(r, g->n), n = copy_n(n, g->n), out = copy_n(out, g->n)](int i) {
+        return ec_binop(op, lt, l[i], rt, r[i], n[i], out[i], g->streams[i]);
+    });
 }
 
 extern "C" ec_status ec_sharded_masked_binop(ec_shard_group* g, ec_op op, ec_dtype lt, const void* const* l, const uint8_t* const* lmask,
@@ -311,9 +451,19 @@ extern "C" ec_status ec_sharded_masked_binop(ec_shard_group* g, ec_op op, ec_dty
     ec_status st = check_group(g, "ec_sharded_masked_binop");
     if (st != EC_OK) return st;
     if (!l || !lmask || !r || !rmask || !n || !out || !out_mask) return set_error(EC_ERR_ARG, "ec_sharded_masked_binop: null argument");
+    if (op < EC_ADD || op > EC_DIV) return set_error(EC_ERR_ARG, "ec_sharded_masked_binop: bad op");
+    if (!ecl::valid(lt) || !ecl::valid(rt)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_sharded_masked_binop: bad dtype");
+    const char* what = "ec_sharded_masked_binop";
+    if ((st = check_shard_ptrs(g, what, "l", l, n)) != EC_OK) return st;
+    if ((st = check_shard_ptrs(g, what, "r", r, n)) != EC_OK) return st;
+    if ((st = check_shard_ptrs(g, what, "lmask", reinterpret_cast<const void* const*>(lmask), n)) != EC_OK) return st;
+    if ((st = check_shard_ptrs(g, what, "rmask", reinterpret_cast<const void* const*>(rmask), n)) != EC_OK) return st;
+    if ((st = check_shard_ptrs(g, what, "out", reinterpret_cast<const void* const*>(out), n)) != EC_OK) return st;
+    if ((st = check_shard_ptrs(g, what, "out_mask", reinterpret_cast<const void* const*>(out_mask), n)) != EC_OK) return st;
     std::lock_guard<std::mutex> lk(g->call_mu);
-    return for_each_shard(g, [&](int i) {
-        return ec_masked_binop(op, lt, l[i], lmask[i], rt, r[i], rmask[i], n[i], out[i], out_mask[i], g->streams[i]);
+    return post_each_shard(g, [g, op, lt, rt, l = copy_n(l, g->n), lm = copy_n(lmask, g->n), r = copy_n(r, g->n), rm = copy_n(rmask, g->n),
+                               n = copy_n(n, g->n), out = copy_n(out, g->n), om = copy_n(out_mask, g->n)](int i) {
+        return ec_masked_binop(op, lt, l[i], lm[i], rt, r[i], rm[i], n[i], out[i], om[i], g->streams[i]);
     });
 }
 
@@ -321,10 +471,15 @@ extern "C" ec_status ec_sharded_convert(ec_shard_group* g, ec_dtype st_, const v
                                         const size_t* n) {
     ec_status st = check_group(g, "ec_sharded_convert");
     if (st != EC_OK) return st;
+    if (!ecl::valid(st_) || !ecl::valid(dt)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_sharded_convert: bad dtype");
     if (!ec_can_fit_into(st_, dt)) return ec_convert(st_, nullptr, dt, nullptr, 0, nullptr);  // EC_ERR_NARROWING, before any device work
     if (!src || !dst || !n) return set_error(EC_ERR_ARG, "ec_sharded_convert: null argument");
+    if ((st = check_shard_ptrs(g, "ec_sharded_convert", "src", src, n)) != EC_OK) return st;
+    if ((st = check_shard_ptrs(g, "ec_sharded_convert", "dst", dst, n)) != EC_OK) return st;
     std::lock_guard<std::mutex> lk(g->call_mu);
-    return for_each_shard(g, [&](int i) { return ec_convert(st_, src[i], dt, dst[i], n[i], g->streams[i]); });
+    return post_each_shard(g, [g, st_, dt, src = copy_n(src, g->n), dst = copy_n(dst, g->n), n = copy_n(n, g->n)](int i) {
+        return ec_convert(st_, src[i], dt, dst[i], n[i], g->streams[i]);
+    });
 }
 
 extern "C" ec_status ec_sharded_mask_from_nodata(ec_shard_group* g, ec_dtype t, const void* const* p, const size_t* n,
@@ -332,8 +487,15 @@ extern "C" ec_status ec_sharded_mask_from_nodata(ec_shard_group* g, ec_dtype t, 
     ec_status st = check_group(g, "ec_sharded_mask_from_nodata");
     if (st != EC_OK) return st;
     if (!p || !n || !mask) return set_error(EC_ERR_ARG, "ec_sharded_mask_from_nodata: null argument");
+    if (!ecl::valid(t)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_sharded_mask_from_nodata: bad dtype");
+    if ((st = check_shard_ptrs(g, "ec_sharded_mask_from_nodata", "p", p, n)) != EC_OK) return st;
+    if ((st = check_shard_ptrs(g, "ec_sharded_mask_from_nodata", "mask", reinterpret_cast<const void* const*>(mask), n)) != EC_OK) return st;
+    const bool has_nd = nd_or_null != nullptr;
+    const ec_value nd = has_nd ? *nd_or_null : ec_value{};
     std::lock_guard<std::mutex> lk(g->call_mu);
-    return for_each_shard(g, [&](int i) { return ec_mask_from_nodata(t, p[i], n[i], nd_or_null, mask[i], g->streams[i]); });
+    return post_each_shard(g, [g, t, has_nd, nd, p = copy_n(p, g->n), n = copy_n(n, g->n), mask = copy_n(mask, g->n)](int i) {
+        return ec_mask_from_nodata(t, p[i], n[i], has_nd ? &nd : nullptr, mask[i], g->streams[i]);
+    });
 }
 
 extern "C" ec_status ec_sharded_fused(ec_shard_group* g, ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void* const* const p[4],
@@ -344,30 +506,70 @@ extern "C" ec_status ec_sharded_fused(ec_shard_group* g, ec_op o1, ec_op o2, ec_
     if (!dt || !p || !n || !out) return set_error(EC_ERR_ARG, "ec_sharded_fused: null argument");
     if ((masks_or_null != nullptr) != (out_mask_or_null != nullptr))
         return set_error(EC_ERR_ARG, "ec_sharded_fused: masks and out_mask go together");
+    const int nops = o3 == static_cast<ec_op>(-1) ? 3 : 4;
+    struct Call {
+        ec_op o1, o2, o3;
+        ec_dtype dt[4];
+        bool has_p[4], has_m[4], masked, has_sc;
+        std::vector<const void*> p[4];
+        std::vector<const uint8_t*> m[4];
+        ec_value sc[4];
+        std::vector<size_t> n;
+        std::vector<double*> out;
+        std::vector<uint8_t*> om;
+    };
+    auto c = std::make_shared<Call>();
+    c->o1 = o1; c->o2 = o2; c->o3 = o3;
+    c->masked = masks_or_null != nullptr;
+    c->has_sc = scalars_or_null != nullptr;
+    for (int k = 0; k < 4; ++k) {
+        c->dt[k] = dt[k];
+        c->has_p[k] = k < nops && p[k] != nullptr;
+        c->has_m[k] = c->has_p[k] && masks_or_null && masks_or_null[k] != nullptr;
+        if (c->has_p[k]) {
+            if ((st = check_shard_ptrs(g, "ec_sharded_fused", "p[k]", p[k], n)) != EC_OK) return st;
+            c->p[k] = copy_n(p[k], g->n);
+        }
+        if (c->has_m[k]) c->m[k] = copy_n(masks_or_null[k], g->n);
+        c->sc[k] = scalars_or_null ? scalars_or_null[k] : ec_value{};
+    }
+    if ((st = check_shard_ptrs(g, "ec_sharded_fused", "out", reinterpret_cast<const void* const*>(out), n)) != EC_OK) return st;
+    c->n = copy_n(n, g->n);
+    c->out = copy_n(out, g->n);
+    if (out_mask_or_null) c->om = copy_n(out_mask_or_null, g->n);
     std::lock_guard<std::mutex> lk(g->call_mu);
-    return for_each_shard(g, [&](int i) {
+    return post_each_shard(g, [g, c](int i) {
         const void* pi[4];
         const uint8_t* mi[4];
         for (int k = 0; k < 4; ++k) {
-            pi[k] = p[k] ? p[k][i] : nullptr;  // p[k] == NULL: operand k is the scalar scalars[k]
-            mi[k] = (masks_or_null && masks_or_null[k]) ? masks_or_null[k][i] : nullptr;
+            pi[k] = c->has_p[k] ? c->p[k][i] : nullptr;  // no pointer array: operand k is the scalar scalars[k]
+            mi[k] = c->has_m[k] ? c->m[k][i] : nullptr;
         }
-        if (masks_or_null) return ec_masked_fused(o1, o2, o3, dt, pi, mi, scalars_or_null, n[i], out[i], out_mask_or_null[i], g->streams[i]);
-        return ec_fused(o1, o2, o3, dt, pi, scalars_or_null, n[i], out[i], g->streams[i]);
+        const ec_value* sc = c->has_sc ? c->sc : nullptr;
+        if (c->masked) return ec_masked_fused(c->o1, c->o2, c->o3, c->dt, pi, mi, sc, c->n[i], c->out[i], c->om[i], g->streams[i]);
+        return ec_fused(c->o1, c->o2, c->o3, c->dt, pi, sc, c->n[i], c->out[i], g->streams[i]);
     });
 }
 
+// ---- reductions: synchronous, phased (see the head of this file)
 extern "C" ec_status ec_sharded_min_max(ec_shard_group* g, ec_dtype t, const void* const* p, const uint8_t* const* masks_or_null,
                                         const size_t* n, ec_value* mn, ec_value* mx) {
     ec_status st = check_group(g, "ec_sharded_min_max");
     if (st != EC_OK) return st;
     if (!p || !n || !mn || !mx) return set_error(EC_ERR_ARG, "ec_sharded_min_max: null argument");
+    if (!ecl::valid(t)) return set_error(EC_ERR_UNSUPPORTED_TYPE, "ec_sharded_min_max: bad dtype");
+    if ((st = check_shard_ptrs(g, "ec_sharded_min_max", "p", p, n)) != EC_OK) return st;
+    if (masks_or_null && (st = check_shard_ptrs(g, "ec_sharded_min_max", "masks", reinterpret_cast<const void* const*>(masks_or_null), n)) != EC_OK) return st;
     std::lock_guard<std::mutex> lk(g->call_mu);
+    // phase 1: local reductions everywhere (an empty shard contributes the idempotent sentinels (T::MAX, T::MIN): src/buffer.rs:170)
     st = for_each_shard(g, [&](int i) {
-        // an empty shard contributes the idempotent sentinels (T::MAX, T::MIN): src/buffer.rs:170
-        ec_status s = ec_min_max_keys(t, p[i], masks_or_null ? masks_or_null[i] : nullptr, n[i], g->payload_dev[i], g->streams[i]);
-        return s == EC_OK ? exchange(g, i, true) : s;
+        return ec_min_max_keys(t, p[i], masks_or_null ? masks_or_null[i] : nullptr, n[i], g->payload_dev[i], g->streams[i]);
     });
+    const std::string keep = last_error_text();
+    const ec_status deferred = take_deferred(g);  // an earlier fire-and-forget call that failed: its output may feed this reduction
+    if (deferred != EC_OK) return deferred;
+    if (st != EC_OK) return set_error_text(st, keep);  // nothing was enqueued on any communicator
+    st = exchange(g, true);
     if (st != EC_OK) return st;
     int64_t keys[2] = {g->payload_host[0][0], g->payload_host[0][1]};
     if (g->comms.empty())  // host combine: element-wise MAX of {~key(min), key(max)}
@@ -383,11 +585,16 @@ extern "C" ec_status ec_sharded_counts(ec_shard_group* g, const uint8_t* const* 
     ec_status st = check_group(g, "ec_sharded_counts");
     if (st != EC_OK) return st;
     if (!masks || !n || !n_true || !n_false) return set_error(EC_ERR_ARG, "ec_sharded_counts: null argument");
+    if ((st = check_shard_ptrs(g, "ec_sharded_counts", "masks", reinterpret_cast<const void* const*>(masks), n)) != EC_OK) return st;
     std::lock_guard<std::mutex> lk(g->call_mu);
     st = for_each_shard(g, [&](int i) {
-        ec_status s = ec_mask_counts_device(masks[i], n[i], reinterpret_cast<uint64_t*>(g->payload_dev[i]), g->streams[i]);
-        return s == EC_OK ? exchange(g, i, false) : s;
+        return ec_mask_counts_device(masks[i], n[i], reinterpret_cast<uint64_t*>(g->payload_dev[i]), g->streams[i]);
     });
+    const std::string keep = last_error_text();
+    const ec_status deferred = take_deferred(g);
+    if (deferred != EC_OK) return deferred;
+    if (st != EC_OK) return set_error_text(st, keep);
+    st = exchange(g, false);
     if (st != EC_OK) return st;
     uint64_t a = static_cast<uint64_t>(g->payload_host[0][0]), b = static_cast<uint64_t>(g->payload_host[0][1]);
     if (g->comms.empty())

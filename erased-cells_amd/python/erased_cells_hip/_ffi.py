@@ -100,6 +100,7 @@ SIGNATURES = {
     "ec_shard_group_shard": (I32, [VP, I32, C.POINTER(I32), PVP]),
     "ec_shard_group_foreach": (I32, [VP, SHARD_FN, VP]),
     "ec_shard_group_sync": (I32, [VP]),
+    "ec_shard_group_stat": (I32, [VP, C.c_char_p, C.POINTER(C.c_int64)]),
     "ec_sharded_alloc": (I32, [VP, PSZ, PVP]),
     "ec_sharded_free": (I32, [VP, PVP]),
     "ec_sharded_upload": (I32, [VP, PVP, VP, PSZ, PSZ]),

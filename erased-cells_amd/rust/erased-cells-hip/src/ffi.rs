@@ -125,6 +125,7 @@ extern "C" {
     pub fn ec_shard_group_shard(g: *const ec_shard_group, shard: i32, device: *mut i32, stream: *mut ec_stream) -> ec_status;
     pub fn ec_shard_group_foreach(g: *mut ec_shard_group, f: ec_shard_fn, user: *mut c_void) -> ec_status;
     pub fn ec_shard_group_sync(g: *mut ec_shard_group) -> ec_status;
+    pub fn ec_shard_group_stat(g: *const ec_shard_group, key: *const c_char, value: *mut i64) -> ec_status;
     pub fn ec_sharded_alloc(g: *mut ec_shard_group, bytes: *const usize, dptrs: *mut *mut c_void) -> ec_status;
     pub fn ec_sharded_free(g: *mut ec_shard_group, dptrs: *const *mut c_void) -> ec_status;
     pub fn ec_sharded_upload(g: *mut ec_shard_group, dst_dev: *const *mut c_void, src_host: *const c_void,

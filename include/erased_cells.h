@@ -180,9 +180,12 @@ ec_status ec_fill(ec_dtype t, void *dst, size_t n, const ec_value *value, ec_str
  * term is z alone (`(x o1 y) o2 z`, e.g. `(a + b) * c`) and dt[3]/p[3] are ignored.  Operands may alias.
  * An operand with p[k] == NULL is the scalar `scalars[k]` (the RHS-scalar form of src/buffer.rs:346-352,
  * e.g. `(buf + ones) * 2.0`, examples/masked.rs:12); at least one operand must be a buffer; `n` is the
- * shortest buffer operand's length.  Buffer operands of one cell type run as a single pass with no
- * allocation; operands of mixed cell types are first widened to their CellType::union (the reference's
- * `unify`, src/value.rs:103-107) into temporaries from the stream-ordered pool, freed in stream order. */
+ * shortest buffer operand's length.  Every call is ONE pass over its operands with no allocation and no
+ * synchronisation — whatever the mix of cell types, aliases and scalars — so every call can be captured in a
+ * hipGraph: operands of one cell type run a kernel specialised for that type and op triple, every other mix a
+ * kernel specialised for the operands' byte widths that widens each cell to f64 in registers (the reference's
+ * `unify` + `to_f64`, src/value.rs:103-107,207).  (ec_tune_set("fused_mixed", 0) selects the comparison path of
+ * rounds 1-2 instead: convert mixed operands to their CellType::union into pooled temporaries, then fuse.) */
 #define EC_OP_NONE (-1)
 ec_status ec_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], const void *const p[4],
                    const ec_value *scalars_or_null, size_t n, double *out, ec_stream stream);
@@ -231,11 +234,25 @@ ec_status ec_allreduce_counts(ec_comm comm, uint64_t *counts2_dev, ec_stream str
 
 /* A shard group: one process driving n GPUs — per device a launch thread bound to it, a stream, a 32-byte payload
  * slot and (unless EC_GROUP_HOST_COMBINE) an RCCL communicator of the n-device clique.  Shard i of every sharded
- * call lives on device i of the group.  The per-device threads issue their launches concurrently, so a fan-out
- * costs one launch latency, not n.  EC_GROUP_HOST_COMBINE folds the n 16-byte payloads on the host instead of
- * over xGMI (no RCCL needed; also the only way to list one device twice, e.g. to rehearse on a 1-GPU box). */
+ * call lives on device i of the group.
+ *   Element-wise calls (ec_sharded_binop, _masked_binop, _convert, _mask_from_nodata, _fused) are fire-and-forget:
+ * the arguments are checked on the calling thread (EC_ERR_ARG / EC_ERR_UNSUPPORTED_TYPE / EC_ERR_NARROWING come back at
+ * once), the per-shard pointer arrays are copied, one job per device is queued for its launch thread, and the call
+ * returns without waiting for the launches to be issued: the host can queue the next call while the threads issue
+ * this one side by side (host cost per call and per device: profiles/r03/group_fanout.md).  Calls on one group are
+ * issued on every device in the order they were made.  A failure inside a queued job (a launch error) is kept by
+ * the group and returned — once — by the next ec_shard_group_sync, ec_sharded_min_max or ec_sharded_counts.
+ * The device memory named in a call must stay allocated until the group has been synchronised or it is released
+ * through ec_sharded_free (which queues behind the launches).  EC_GROUP_BLOCKING_ISSUE restores the form of rounds
+ * 1-2: every call waits until all launch threads have issued and returns their first failing status itself.
+ *   The reductions return a value and therefore wait; they run in phases (check every shard's arguments, reduce
+ * locally on every shard, and only when all of that succeeded exchange the payloads), so a shard that fails cannot
+ * leave the others waiting inside a collective.  Should a communicator fail between the ranks' enqueues, the group
+ * is poisoned (communicators aborted, every later call EC_ERR_RCCL) rather than left to hang.
+ *   EC_GROUP_HOST_COMBINE folds the n 16-byte payloads on the host instead of over xGMI (no RCCL needed; also the
+ * only way to list one device twice, e.g. to rehearse on a 1-GPU box). */
 typedef struct ec_shard_group ec_shard_group;
-enum { EC_GROUP_RCCL = 0, EC_GROUP_HOST_COMBINE = 1 };
+enum { EC_GROUP_RCCL = 0, EC_GROUP_HOST_COMBINE = 1, EC_GROUP_BLOCKING_ISSUE = 2 };
 ec_status ec_shard_group_create(const int32_t *devices, int32_t n, uint32_t flags, ec_shard_group **out);
 ec_status ec_shard_group_destroy(ec_shard_group *g);
 int32_t ec_shard_group_size(const ec_shard_group *g);
@@ -247,7 +264,11 @@ ec_status ec_shard_group_shard(const ec_shard_group *g, int32_t shard, int32_t *
  * destroy every group before ec_shutdown().) */
 typedef ec_status (*ec_shard_fn)(int32_t shard, int32_t device, ec_stream stream, void *user);
 ec_status ec_shard_group_foreach(ec_shard_group *g, ec_shard_fn fn, void *user);
-ec_status ec_shard_group_sync(ec_shard_group *g); /* waits for every shard's stream */
+/* Waits until everything queued so far has been issued and every shard's stream has drained; returns (and clears)
+ * the first failure a fire-and-forget call left behind. */
+ec_status ec_shard_group_sync(ec_shard_group *g);
+/* Counters of a group: "jobs_posted" (fire-and-forget jobs queued so far), "poisoned", "blocking_issue". */
+ec_status ec_shard_group_stat(const ec_shard_group *g, const char *key, int64_t *value);
 /* Per-shard device blocks (bytes[i] on device i) and the scatter / gather of one host buffer by byte ranges
  * (`From<Vec<T>>` / `to_vec` of a sharded buffer; the ranges come from ec_shard_range x sizeof(T)). */
 ec_status ec_sharded_alloc(ec_shard_group *g, const size_t *bytes, void **dptrs);
@@ -256,14 +277,14 @@ ec_status ec_sharded_upload(ec_shard_group *g, void *const *dst_dev, const void 
                             const size_t *byte_offsets, const size_t *bytes);
 ec_status ec_sharded_download(ec_shard_group *g, void *dst_host, const void *const *src_dev,
                               const size_t *byte_offsets, const size_t *bytes);
-/* impl {Add,Sub,Mul,Div} for &CellBuffer (src/buffer.rs:324-329) on every shard; asynchronous, no communication. */
+/* impl {Add,Sub,Mul,Div} for &CellBuffer (src/buffer.rs:324-329) on every shard; fire-and-forget, no communication. */
 ec_status ec_sharded_binop(ec_shard_group *g, ec_op op, ec_dtype lt, const void *const *l, ec_dtype rt,
                            const void *const *r, const size_t *n, double *const *out);
 /* The other element-wise entry points on every shard, same arguments as their one-GPU forms with one pointer per
  * shard: impl $trt for &MaskedCellBuffer (src/masked/masked_buffer.rs:326-335), BufferOps::convert
  * (src/buffer.rs:150-167; EC_ERR_NARROWING before any device work), from_vec_with_nodata
  * (src/masked/masked_buffer.rs:62-71), and the fused chains — p[k] is operand k's per-shard pointer array, or NULL
- * for a scalar operand (scalars[k]); masks_or_null / out_mask_or_null both given or both NULL.  Asynchronous. */
+ * for a scalar operand (scalars[k]); masks_or_null / out_mask_or_null both given or both NULL.  Fire-and-forget. */
 ec_status ec_sharded_masked_binop(ec_shard_group *g, ec_op op, ec_dtype lt, const void *const *l,
                                   const uint8_t *const *lmask, ec_dtype rt, const void *const *r,
                                   const uint8_t *const *rmask, const size_t *n, double *const *out,

@@ -161,6 +161,103 @@ def test_shard_group_from_python_matches_oracle(ec):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("blocking", [0, 2], ids=["fire-and-forget", "blocking-issue"])
+def test_shard_group_calls_are_issued_in_order_and_failures_do_not_hang(ec, blocking):
+    """Round 3: element-wise sharded calls return once their jobs are queued.  (1) A chain of dependent calls — each
+    reads what the one before wrote, the ctypes argument arrays of each call are dropped at once — gives the oracle's
+    result: the per-shard pointers are copied and every device issues in call order.  (2) A shard that cannot take part
+    in a reduction (NULL pointer with cells to read) is refused on the calling thread with EC_ERR_ARG — before any
+    launch thread has enqueued a collective, so nothing waits for a missing rank (round 2: the other shards hung).
+    (3) A failure inside a queued job is kept by the group and returned once by the next sync / reduction."""
+    from erased_cells_hip import sharded
+    from vectors import rand_cells
+    L, chk, E = ec.lib(), ec._ffi.check, ec._ffi
+    G, rows, cols = 3, 41, 257
+    a = rand_cells(eco.U16, rows * cols, 31, specials=False)
+    a[a == 0] = 1
+    grp = C.c_void_p()
+    chk(L.ec_shard_group_create((C.c_int32 * G)(*([0] * G)), G, 1 | blocking, C.byref(grp)))
+    try:
+        v = C.c_int64(-1)
+        chk(L.ec_shard_group_stat(grp, b"blocking_issue", C.byref(v)))
+        assert v.value == (1 if blocking else 0)
+        rng = [sharded.shard_range(rows, cols, g, G) for g in range(G)]
+        lens = [r[1] for r in rng]
+
+        def sizes(item):
+            return (C.c_size_t * G)(*[ln * item for ln in lens])
+
+        def offs(item):
+            return (C.c_size_t * G)(*[r[0] * item for r in rng])
+
+        da, t0, t1 = (C.c_void_p * G)(), (C.c_void_p * G)(), (C.c_void_p * G)()
+        chk(L.ec_sharded_alloc(grp, sizes(2), da))
+        chk(L.ec_sharded_alloc(grp, sizes(8), t0))
+        chk(L.ec_sharded_alloc(grp, sizes(8), t1))
+        chk(L.ec_sharded_upload(grp, da, a.ctypes.data_as(C.c_void_p), offs(2), sizes(2)))
+        # (1) t0 = a + a; then 24 dependent steps t_next = t_prev op a, ping-pong between t0 and t1
+        chk(L.ec_shard_group_stat(grp, b"jobs_posted", C.byref(v)))
+        posted0 = v.value
+        chk(L.ec_sharded_binop(grp, eco.ADD, eco.U16, (C.c_void_p * G)(*da), eco.U16, (C.c_void_p * G)(*da), (C.c_size_t * G)(*lens), (C.c_void_p * G)(*t0)))
+        exp = eco.f_binop(eco.ADD, a, a)
+        src, dst = t0, t1
+        for k in range(24):
+            op = (eco.MUL, eco.SUB, eco.DIV, eco.ADD)[k % 4]
+            chk(L.ec_sharded_binop(grp, op, eco.F64, (C.c_void_p * G)(*src), eco.U16, (C.c_void_p * G)(*da), (C.c_size_t * G)(*lens),
+                                   (C.c_void_p * G)(*dst)))  # temporaries: gone when the call returns
+            exp = eco.f_binop(op, exp, a)
+            src, dst = dst, src
+        chk(L.ec_shard_group_stat(grp, b"jobs_posted", C.byref(v)))
+        assert v.value - posted0 == (0 if blocking else 25 * G)
+        back = np.empty(rows * cols, np.float64)
+        chk(L.ec_sharded_download(grp, back.ctypes.data_as(C.c_void_p), src, offs(8), sizes(8)))  # queued behind the launches
+        assert np.array_equal(back.view(np.uint64), exp.view(np.uint64))
+        # (2) arguments are checked before any fan-out
+        n = (C.c_size_t * G)(*lens)
+        holed = (C.c_void_p * G)(*da)
+        holed[1] = None
+        mn, mx = E.EcValue(), E.EcValue()
+        t, f = C.c_uint64(), C.c_uint64()
+        assert L.ec_sharded_min_max(grp, eco.U16, holed, None, n, C.byref(mn), C.byref(mx)) == E.EC_ERR_ARG
+        assert b"p[1] is null" in L.ec_last_error_string()
+        assert L.ec_sharded_min_max(grp, eco.U16, da, holed, n, C.byref(mn), C.byref(mx)) == E.EC_ERR_ARG
+        assert L.ec_sharded_counts(grp, holed, n, C.byref(t), C.byref(f)) == E.EC_ERR_ARG
+        assert L.ec_sharded_binop(grp, eco.ADD, eco.U16, holed, eco.U16, da, n, t0) == E.EC_ERR_ARG
+        assert L.ec_sharded_binop(grp, eco.ADD, eco.U16, da, eco.U16, da, n, holed) == E.EC_ERR_ARG
+        assert L.ec_sharded_binop(grp, eco.ADD, 10, da, eco.U16, da, n, t0) == E.EC_ERR_UNSUPPORTED_TYPE
+        assert L.ec_sharded_min_max(grp, 10, da, None, n, C.byref(mn), C.byref(mx)) == E.EC_ERR_UNSUPPORTED_TYPE
+        assert L.ec_sharded_convert(grp, eco.F64, t0, eco.U16, da, n) == E.EC_ERR_NARROWING
+        empty_ok = (C.c_size_t * G)(lens[0], 0, lens[2])  # ... but a shard with no cells may have no pointer
+        chk(L.ec_sharded_min_max(grp, eco.U16, holed, None, empty_ok, C.byref(mn), C.byref(mx)))
+        part = np.concatenate([a[rng[0][0]:rng[0][0] + lens[0]], a[rng[2][0]:rng[2][0] + lens[2]]])
+        emn, emx = eco.f_min_max(part)
+        assert (ec.CellValue.from_ec(mn).bits(), ec.CellValue.from_ec(mx).bits()) == (emn.bits(), emx.bits())
+        # the group is still usable
+        chk(L.ec_sharded_min_max(grp, eco.U16, da, None, n, C.byref(mn), C.byref(mx)))
+        emn, emx = eco.f_min_max(a)
+        assert (ec.CellValue.from_ec(mn).bits(), ec.CellValue.from_ec(mx).bits()) == (emn.bits(), emx.bits())
+        # (3) a job that fails after the call has returned
+        if not blocking:
+            chk(L.ec_tune_set(b"inject_shard_failure", 2))  # shard 1's next job
+            chk(L.ec_sharded_binop(grp, eco.ADD, eco.U16, da, eco.U16, da, n, t0))  # returns EC_OK: only queued
+            st = L.ec_shard_group_sync(grp)
+            assert st == E.EC_ERR_HIP and b"shard 1" in L.ec_last_error_string() and b"injected" in L.ec_last_error_string()
+            chk(L.ec_shard_group_sync(grp))  # reported once
+            chk(L.ec_tune_set(b"inject_shard_failure", 1))
+            chk(L.ec_sharded_binop(grp, eco.ADD, eco.U16, da, eco.U16, da, n, t0))
+            assert L.ec_sharded_min_max(grp, eco.F64, t0, None, n, C.byref(mn), C.byref(mx)) == E.EC_ERR_HIP  # its input is suspect
+            chk(L.ec_sharded_min_max(grp, eco.U16, da, None, n, C.byref(mn), C.byref(mx)))
+        chk(L.ec_shard_group_stat(grp, b"poisoned", C.byref(v)))
+        assert v.value == 0
+        for p in (da, t0, t1):
+            chk(L.ec_sharded_free(grp, p))
+    finally:
+        chk(L.ec_tune_set(b"inject_shard_failure", 0))
+        chk(L.ec_shard_group_destroy(grp))
+
+
+@pytest.mark.gpu
 def test_device_selection_and_pool(ec):
     L, chk = ec.lib(), ec._ffi.check
     dev = C.c_int32(-1)
