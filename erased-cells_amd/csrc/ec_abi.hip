@@ -62,7 +62,8 @@ template <typename Fn, int U>
 static void launch_map_u(const Fn& fn, size_t n, hipStream_t s) {
     const size_t groups = n / Fn::CPL;
     const size_t tiles = (groups + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
-    k_map<Fn, U><<<grid_for(tiles), kBlock, 0, s>>>(fn, n);
+    const size_t stream_bytes[2] = {n * Fn::kIn0, n * Fn::kIn1};
+    k_map<Fn, U><<<grid_for(tiles), kBlock, 0, s>>>(fn, n, cache_plan(stream_bytes, 2));
 }
 
 template <typename Fn>
@@ -140,8 +141,10 @@ static ec_status launch_min_max(const void* p, const uint8_t* mask, size_t n, in
                 if (tiles < 1) tiles = 1;
                 grid = static_cast<unsigned>(tiles < size_t(cap2) ? tiles : size_t(cap2));
                 int64_t* direct = grid == 1 ? keys2_dev : nullptr;  // one workgroup: it writes the result itself
-                if (mask) k_min_max_partials<T, true, U, BLOCK><<<grid, BLOCK, 0, s>>>(tp, mask, n, sc.dev, head, direct);
-                else k_min_max_partials<T, false, U, BLOCK><<<grid, BLOCK, 0, s>>>(tp, nullptr, n, sc.dev, head, direct);
+                const size_t stream_bytes[2] = {n * sizeof(T), mask ? n : 0};
+                const unsigned hp = head | (cache_plan(stream_bytes, 2) << 8);  // leading cells + load policy
+                if (mask) k_min_max_partials<T, true, U, BLOCK><<<grid, BLOCK, 0, s>>>(tp, mask, n, sc.dev, hp, direct);
+                else k_min_max_partials<T, false, U, BLOCK><<<grid, BLOCK, 0, s>>>(tp, nullptr, n, sc.dev, hp, direct);
                 return direct != nullptr;
             };
             using std::integral_constant;
@@ -419,8 +422,9 @@ static ec_status first_diff_w(const void* l, const void* r, size_t n, const Scra
     size_t tiles = al ? ((n - head) / (16 / sizeof(W)) + size_t(kRBlock) * kReduceU - 1) / (size_t(kRBlock) * kReduceU) : (n + kRBlock - 1) / kRBlock;
     if (tiles < 1) tiles = 1;
     const unsigned grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
+    const size_t stream_bytes[2] = {n * sizeof(W), n * sizeof(W)};
     k_first_diff_partials<W, kReduceU><<<grid, kRBlock, 0, s>>>(static_cast<const W*>(l), static_cast<const W*>(r), n,
-                                                               reinterpret_cast<uint64_t*>(sc.dev), al, head);
+                                                               reinterpret_cast<uint64_t*>(sc.dev), al, head | (cache_plan(stream_bytes, 2) << 8));
     *grid_out = grid;
     return check_launch("first_diff(partials)");
 }
@@ -574,7 +578,9 @@ extern "C" ec_status ec_mask_counts_device(const uint8_t* m, size_t n, uint64_t*
         if (tiles < 1) tiles = 1;
         grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
         uint64_t* direct = grid == 1 ? counts2_dev : nullptr;  // one workgroup: it writes the result itself
-        k_mask_count_partials<kReduceU><<<grid, kRBlock, 0, S(stream)>>>(m, n, reinterpret_cast<uint64_t*>(sc.dev), al, head, direct);
+        const size_t stream_bytes[1] = {n};
+        k_mask_count_partials<kReduceU><<<grid, kRBlock, 0, S(stream)>>>(m, n, reinterpret_cast<uint64_t*>(sc.dev), al,
+                                                                        head | (cache_plan(stream_bytes, 1) << 8), direct);
         st = check_launch("mask_counts(partials)");
         if (st != EC_OK || direct) return st;
     }

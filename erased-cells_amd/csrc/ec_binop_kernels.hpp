@@ -57,7 +57,7 @@ __device__ __forceinline__ size_t two_front_tile() {
 // ---------------------------------------------------------------------------
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const R* __restrict__ r,
-                                                  double* __restrict__ out, size_t npairs, size_t tile) {
+                                                  double* __restrict__ out, size_t npairs, size_t tile, unsigned cacheable) {
     using D2 = vec<double, 2>;
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
     constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
@@ -67,11 +67,14 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
     if (tile * TILE + TILE <= npairs) {
         cells<L, 2> a[U];  // 1-byte operands travel as 16-bit words so that their loads keep `nt` (ec_device.hpp)
         cells<R, 2> b[U];
+        policy_arms<2>(cacheable, [&](auto bits) {  // bit 0: l, bit 1: r loaded with the default cache policy (ec_device.hpp)
+            constexpr unsigned B = decltype(bits)::value;
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            a[j] = load_cells<NT_LD, L, 2>(l + 2 * (base + size_t(j) * kBlock));
-            b[j] = load_cells<NT_LD, R, 2>(r + 2 * (base + size_t(j) * kBlock));
-        }
+            for (int j = 0; j < U; ++j) {
+                a[j] = load_cells<NT_LD && !(B & 1u), L, 2>(l + 2 * (base + size_t(j) * kBlock));
+                b[j] = load_cells<NT_LD && !(B & 2u), R, 2>(r + 2 * (base + size_t(j) * kBlock));
+            }
+        });
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             D2 o;
@@ -100,12 +103,15 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
 // exactly ceil(npairs / TILE) workgroups (two_front_tile is a permutation of the tile indices).
 // `head` (0 or 1, chosen by the launcher: peel_head() in ec_runtime.hpp) leading cells are computed one by
 // one by workgroup 0 and the pair grid starts after them, so that the 2-cell loads of 1-byte operands fall on
-// even addresses (measurements and the rule: ec_runtime.hpp).
+// even addresses (measurements and the rule: ec_runtime.hpp).  Bits 8.. of `head` carry the launch's load policy:
+// bit 8 = l, bit 9 = r (masked kernels: bit 10 = lmask, bit 11 = rmask) is loaded cacheable instead of nt
+// (cache_plan(), ec_runtime.hpp; policy_arms(), ec_device.hpp).
 template <typename L, typename R, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const R* __restrict__ r,
-                                                  double* __restrict__ out, size_t n, unsigned head) {
+                                                  double* __restrict__ out, size_t n, unsigned head_and_policy) {
     constexpr bool FP = is_fp<L>::value || is_fp<R>::value;
     constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
+    const unsigned head = head_and_policy & 0xffu, cacheable = head_and_policy >> 8;
     if (head) {
         if (blockIdx.x == 0 && threadIdx.x < head)
             st_cell(cell_op<OP, FP, SM>(to_f64(ld_cell(l + threadIdx.x)), to_f64(ld_cell(r + threadIdx.x))), out + threadIdx.x);
@@ -114,14 +120,14 @@ __device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const
         out += head;
         n -= head;
     }
-    binop_direct_tile<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n >> 1, two_front_tile());
+    binop_direct_tile<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n >> 1, two_front_tile(), cacheable);
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
         st_cell(cell_op<OP, FP, SM>(to_f64(ld_cell(l + n - 1)), to_f64(ld_cell(r + n - 1))), out + n - 1);
 }
 
 template <typename L, int OP, int U, bool NT_ST, bool NT_LD>
 __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, double s, double* __restrict__ out,
-                                                  size_t npairs, size_t tile) {
+                                                  size_t npairs, size_t tile, unsigned cacheable) {
     using D2 = vec<double, 2>;
     constexpr bool FP = true;  // the scalar may be any of the 10 types, widened to f64 on the host
     constexpr size_t TILE = size_t(kBlock) * U;
@@ -129,8 +135,11 @@ __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, doubl
     const size_t base = tile * TILE + threadIdx.x;
     if (tile * TILE + TILE <= npairs) {
         cells<L, 2> a[U];
+        policy_arms<1>(cacheable, [&](auto bits) {
+            constexpr unsigned B = decltype(bits)::value;
 #pragma unroll
-        for (int j = 0; j < U; ++j) a[j] = load_cells<NT_LD, L, 2>(l + 2 * (base + size_t(j) * kBlock));
+            for (int j = 0; j < U; ++j) a[j] = load_cells<NT_LD && !(B & 1u), L, 2>(l + 2 * (base + size_t(j) * kBlock));
+        });
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             D2 o;
@@ -155,14 +164,15 @@ __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, doubl
 
 template <typename L, int OP, int U, bool NT_ST, bool NT_LD>
 __global__ __launch_bounds__(kBlock) void k_binop_scalar_direct(const L* __restrict__ l, double s,
-                                                                double* __restrict__ out, size_t n, unsigned head) {
+                                                                double* __restrict__ out, size_t n, unsigned head_and_policy) {
+    const unsigned head = head_and_policy & 0xffu, cacheable = head_and_policy >> 8;
     if (head) {  // see binop_direct_body
         if (blockIdx.x == 0 && threadIdx.x < head) st_cell(cell_op<OP, true>(to_f64(ld_cell(l + threadIdx.x)), s), out + threadIdx.x);
         l += head;
         out += head;
         n -= head;
     }
-    binop_scalar_tile<L, OP, U, NT_ST, NT_LD>(l, s, out, n >> 1, two_front_tile());
+    binop_scalar_tile<L, OP, U, NT_ST, NT_LD>(l, s, out, n >> 1, two_front_tile(), cacheable);
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) st_cell(cell_op<OP, true>(to_f64(ld_cell(l + n - 1)), s), out + n - 1);
 }
 
@@ -286,14 +296,21 @@ __global__ __launch_bounds__(kBlock) void k_binop_lds(const L* __restrict__ l, c
 
 // `&Mask & &Mask` (src/masked/mask.rs:129-140) as a block-tiled 16-B-per-lane stream.
 __device__ __forceinline__ void mask_and_body(const uint8_t* __restrict__ lm, const uint8_t* __restrict__ rm,
-                                              uint8_t* __restrict__ om, size_t n) {
+                                              uint8_t* __restrict__ om, size_t n, unsigned cacheable) {
     const size_t ngroups = n / 16;
     const u32x4* __restrict__ a = reinterpret_cast<const u32x4*>(lm);
     const u32x4* __restrict__ b = reinterpret_cast<const u32x4*>(rm);
     u32x4* __restrict__ o = reinterpret_cast<u32x4*>(om);
     const size_t stride = size_t(gridDim.x) * kBlock;
-    for (size_t g = size_t(blockIdx.x) * kBlock + threadIdx.x; g < ngroups; g += stride)
-        nt_store(nt_load(a + g) & nt_load(b + g), o + g);
+    for (size_t g = size_t(blockIdx.x) * kBlock + threadIdx.x; g < ngroups; g += stride) {
+        u32x4 x, y;
+        policy_arms<2>(cacheable >> 2, [&](auto bits) {  // bits 2, 3 of the launch's policy: a mask of a 16384² raster is 256 MiB
+            constexpr unsigned B = decltype(bits)::value;
+            x = load_vec<!(B & 1u)>(a + g);
+            y = load_vec<!(B & 2u)>(b + g);
+        });
+        nt_store(x & y, o + g);
+    }
     if (blockIdx.x == 0)
         for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) st_cell<uint8_t>(ld_cell(lm + i) & ld_cell(rm + i), om + i);
 }
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_masked_binop(const L* __restrict__ l
                                                          unsigned head) {
     if constexpr (LDS) binop_lds_body<L, R, OP, NT_ST, NT_LD>(l, r, out, n);
     else binop_direct_body<L, R, OP, U, NT_ST, NT_LD>(l, r, out, n, head);
-    mask_and_body(lm, rm, om, n);
+    mask_and_body(lm, rm, om, n, head >> 8);
 }
 
 template <typename L, typename R, int OP>

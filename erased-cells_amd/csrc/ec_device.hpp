@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "erased_cells.h"
 
 namespace ecd {
@@ -209,5 +211,34 @@ __device__ __forceinline__ cells<T, N> load_cells(const T* first_cell) {
     else return C{plain_load(p)};
 }
 
+// Load policy of a launch.  Non-temporal is right for a stream that is read once (measured on reads that miss every
+// cache: 16 B/lane loads reach 0.865 of the HBM peak with nt against 0.76 with the default policy, which allocates in
+// the 256 MiB Infinity Cache and evicts on the way).  But an operand that FITS the Infinity Cache is worth keeping
+// there: the 256 MiB u8 operand of the 16384² divide, re-read by the next operator on it, is then served on-die (the
+// divide: 0.86 of peak against 0.80 with the same operand fetched from HBM every time; profiles/r03/
+// tune_nt_width_rotating.log) — and when it is not re-read the default policy costs that one stream ≈1 %.  So the HOST
+// decides per launch and per operand stream (cache_plan, ec_runtime.hpp: smallest operands first, while they fit the
+// cache together) and passes one bit per stream: set = default cache policy, clear = nt.
+//
+// policy_arms<NBITS>(policy, leaf) turns the NBITS launch-uniform policy bits into 2^NBITS straight-line ARMS and calls
+// leaf(std::integral_constant<unsigned, BITS>) in the one that matches: the leaf issues ALL operand loads of the tile
+// with compile-time policies.  Two things make that shape necessary.  (1) One arm holds every stream's loads: with
+// a branch per stream the first use of stream A's cells is scheduled inside A's arms and waits for A before B's
+// loads are issued.  (2) The arms differ only in the loads' `!nontemporal` metadata, and LLVM merges such twins
+// (SimplifyCFG hoists / sinks "identical" instructions out of the arms and keeps only the metadata they share — the
+// launch would then run default-policy loads whatever the host asked for; tools/isa_audit.py caught exactly that).  An
+// asm statement that clobbers memory and carries the arm's number brackets every arm with a default-policy load: loads
+// cannot move across it and no two brackets are identical, so the arms stay apart.  It emits a comment, no instruction.
+template <int NBITS, unsigned ACC = 0, typename Leaf>
+__device__ __forceinline__ void policy_arms(unsigned policy, Leaf&& leaf) {
+    if constexpr (NBITS == 0) {
+        if constexpr (ACC != 0) asm volatile("; load-policy arm %0" ::"n"(ACC) : "memory");
+        leaf(std::integral_constant<unsigned, ACC>{});
+        if constexpr (ACC != 0) asm volatile("; end of load-policy arm %0" ::"n"(ACC) : "memory");
+    } else {
+        if (policy & (1u << (NBITS - 1))) policy_arms<NBITS - 1, (ACC | (1u << (NBITS - 1)))>(policy, leaf);
+        else policy_arms<NBITS - 1, ACC>(policy, leaf);
+    }
+}
 
 }  // namespace ecd

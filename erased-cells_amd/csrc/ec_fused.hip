@@ -1,17 +1,11 @@
 // ec_fused.hip — ABI entry points of the fused two-level expression kernels: operand set-up (aliases, scalars, masks) and
-// dispatch.  Buffer operands of ONE cell type run the kernels specialised per type and op triple (ec_fused_kernels.hpp);
-// every other mix of cell types runs k_fused_any (ec_fused_any.hpp: load classes at compile time, kinds and ops
-// launch-uniform) — one pass, no temporaries, for all of them.
+// dispatch to k_fused_any (ec_fused_any.hpp: load classes at compile time, kinds and ops launch-uniform) — one pass, no
+// temporaries, for every mix of operand cell types.
 #include <hip/hip_runtime.h>
 
 #include "ec_fused_any.hpp"
 #include "ec_lattice.hpp"
 #include "ec_runtime.hpp"
-
-namespace ecd {
-template <int O2>
-void dispatch_fused(const FusedArgs& fa, int same_dt, unsigned grid, double* out, uint8_t* out_mask, size_t n, hipStream_t s);
-}
 
 using namespace ecd;
 
@@ -41,6 +35,10 @@ static ec_status launch_fused_any(FusedArgs& fa, int nops, size_t n, double* out
     }
     fa.small = small ? 1 : 0;
     fa.head = static_cast<uint8_t>(fused_head(fa, n));
+    size_t stream_bytes[8];
+    for (int k = 0; k < 4; ++k) stream_bytes[k] = n * size_t(fused_class_bytes(cls[k]));  // 0: no stream of its own
+    for (int j = 0; j < 4; ++j) stream_bytes[4 + j] = j < fa.nmask ? n : 0;
+    fa.cacheable = static_cast<uint8_t>(cache_plan(stream_bytes, 8));
     const size_t per_tile = size_t(kBlock) * fused_u(narrowest);
     const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
     FusedAnyKernel kern = nullptr;
@@ -107,16 +105,11 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         k_fused_cellwise<0><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(fa, out, out_mask, n);
         return check_launch("fused(cellwise)");
     }
-    bool same_type = true;
-    for (int k = 0; k < 4; ++k)
-        if (!fa.is_sc[k] && fa.dt[k] != fa.dt[first_buf]) same_type = false;
-    const int mixed_mode = tuning().fused_mixed;  // 1 (default): k_fused_any for mixed cell types; 2: for every call; 0: convert, then fuse
-    if (mixed_mode == 2 || (mixed_mode == 1 && !same_type)) return launch_fused_any(fa, nops, n, out, out_mask, s);
-    fa.head = 0;
+    if (tuning().fused_mixed != 0) return launch_fused_any(fa, nops, n, out, out_mask, s);
     // fused_mixed == 0 — the comparison path of rounds 1-2, kept for A/B runs and as a second implementation the tests
-    // hold k_fused_any against: widen every buffer operand to the common CellType::union first (the reference's
-    // `unify`, value-preserving — SURVEY App. A.1) into temporaries from the stream-ordered pool, then run the same-type
-    // kernel.  Same-type calls convert and allocate nothing.
+    // hold the one-pass form against: widen every buffer operand to the common CellType::union first (the reference's
+    // `unify`, value-preserving — SURVEY App. A.1) into temporaries from the stream-ordered pool, then run the kernel on
+    // operands of one cell type.  Same-type calls convert and allocate nothing.
     int u = fa.dt[first_buf];
     for (int k = 0; k < 4; ++k)
         if (!fa.is_sc[k]) u = ecl::union_of(u, fa.dt[k]);
@@ -135,18 +128,7 @@ static ec_status launch_fused(int o1, int o2, int o3, const ec_dtype dt[4], cons
         fa.p[k] = temps[k];
         fa.dt[k] = static_cast<int8_t>(u);
     }
-    if (st == EC_OK) {
-        fa.head = static_cast<uint8_t>(fused_head(fa, n));  // (operands are same-typed by now)
-        const size_t per_tile = size_t(kBlock) * fused_u(ecl::size_of(u));
-        const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
-        switch (o2) {
-            case EC_ADD: dispatch_fused<EC_ADD>(fa, u, grid, out, out_mask, n, s); break;
-            case EC_SUB: dispatch_fused<EC_SUB>(fa, u, grid, out, out_mask, n, s); break;
-            case EC_MUL: dispatch_fused<EC_MUL>(fa, u, grid, out, out_mask, n, s); break;
-            default: dispatch_fused<EC_DIV>(fa, u, grid, out, out_mask, n, s); break;
-        }
-        st = check_launch("fused");
-    }
+    if (st == EC_OK) st = launch_fused_any(fa, nops, n, out, out_mask, s);
     for (int k = 0; k < 4; ++k)
         if (temps[k]) (void)ec_free_async(temps[k], s);  // stream-ordered: released after the kernel
     return st;

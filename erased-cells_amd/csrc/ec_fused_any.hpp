@@ -1,10 +1,11 @@
 // ec_fused_any.hpp — the fused two-level expression  out = (x o1 y) o2 (z o3 w)  over operands of ANY mix of the ten
 // cell types, in one pass (gfx950).  Round 3: fused coverage by construction instead of by enumeration.
 //
-// Rounds 1-2 instantiated one kernel per cell type and op triple (k_fused_same) and, for operands of two cell types, one
-// per (ordered type pair, slot pattern, op triple) for 12 chosen pairs (k_fused_mixed: 1,344 kernels); every other mix —
-// 78 of the 90 ordered pairs, A A B B, three or four cell types — paid a convert pass per narrower operand through pooled
-// temporaries (22 instead of 14 B/cell on NDVI u16 + f32, an allocation inside the call, no hipGraph capture).
+// Rounds 1-2 instantiated one kernel per cell type and op triple (k_fused_same: 800) and, for operands of two cell
+// types, one per (ordered type pair, slot pattern, op triple) for 12 chosen pairs (k_fused_mixed: 1,344); every other
+// mix — 78 of the 90 ordered pairs, A A B B, three or four cell types — paid a convert pass per narrower operand through
+// pooled temporaries (22 instead of 14 B/cell on NDVI u16 + f32, an allocation inside the call, no hipGraph capture).
+// This one family replaces all of them (and runs faster than the specialised kernels did: ec_fused_kernels.hpp).
 //
 // What the memory system needs to know at compile time is only each operand stream's WIDTH: a lane's pair of cells is
 // one 2-, 4-, 8- or 16-byte load whatever the cells mean.  So a slot has a compile-time LOAD CLASS (the cell width in
@@ -142,7 +143,7 @@ __host__ __device__ constexpr int fused_any_min_class(int a, int b, int c, int d
 //             the 2-add + 6-instruction exact divide of ec_fused_kernels.hpp (proven on the whole operand square)
 template <int CX, int CY, int CZ, int CW>
 __global__ __launch_bounds__(kBlock) void k_fused_any(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
-    constexpr int U = fused_u(size_t(fused_any_min_class(CX, CY, CZ, CW)));  // pairs per lane per tile, by the narrowest stream
+    constexpr int U = fused_u(size_t(fused_any_min_class(CX, CY, CZ, CW)));  // pairs per lane per tile (2: ec_fused_kernels.hpp)
     constexpr int NC = 2 * U;
     const unsigned head = fa.head;
     const size_t npairs = (n - head) >> 1;
@@ -162,14 +163,36 @@ __global__ __launch_bounds__(kBlock) void k_fused_any(FusedArgs fa, double* __re
     typename raw_pair<CY>::type ry[U] = {};
     typename raw_pair<CZ>::type rz[U] = {};
     typename raw_pair<CW>::type rw[U] = {};
+    if (full) {
+        // launch-uniform load policy (policy_arms, ec_device.hpp): the bits of the slots that HAVE a stream, packed
+        constexpr int kStreams = (CX != 0) + (CY != 0) + (CZ != 0) + (CW != 0);
+        constexpr int kBitY = (CX != 0), kBitZ = kBitY + (CY != 0), kBitW = kBitZ + (CZ != 0);
+        unsigned packed = 0;
+        if constexpr (CX != 0) packed |= (fa.cacheable & 1u);
+        if constexpr (CY != 0) packed |= ((fa.cacheable >> 1) & 1u) << kBitY;
+        if constexpr (CZ != 0) packed |= ((fa.cacheable >> 2) & 1u) << kBitZ;
+        if constexpr (CW != 0) packed |= ((fa.cacheable >> 3) & 1u) << kBitW;
+        policy_arms<kStreams>(packed, [&](auto bits) {
+            constexpr unsigned B = decltype(bits)::value;
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-        const size_t pr = base + size_t(j) * kBlock;
-        if (full || pr < npairs) {
-            if constexpr (CX != 0) rx[j] = nt_load(reinterpret_cast<const typename raw_pair<CX>::type*>(bx) + pr);
-            if constexpr (CY != 0) ry[j] = nt_load(reinterpret_cast<const typename raw_pair<CY>::type*>(by) + pr);
-            if constexpr (CZ != 0) rz[j] = nt_load(reinterpret_cast<const typename raw_pair<CZ>::type*>(bz) + pr);
-            if constexpr (CW != 0) rw[j] = nt_load(reinterpret_cast<const typename raw_pair<CW>::type*>(bw) + pr);
+            for (int j = 0; j < U; ++j) {
+                const size_t pr = base + size_t(j) * kBlock;
+                if constexpr (CX != 0) rx[j] = load_vec<!(B & 1u)>(reinterpret_cast<const typename raw_pair<CX>::type*>(bx) + pr);
+                if constexpr (CY != 0) ry[j] = load_vec<!((B >> kBitY) & 1u)>(reinterpret_cast<const typename raw_pair<CY>::type*>(by) + pr);
+                if constexpr (CZ != 0) rz[j] = load_vec<!((B >> kBitZ) & 1u)>(reinterpret_cast<const typename raw_pair<CZ>::type*>(bz) + pr);
+                if constexpr (CW != 0) rw[j] = load_vec<!((B >> kBitW) & 1u)>(reinterpret_cast<const typename raw_pair<CW>::type*>(bw) + pr);
+            }
+        });
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const size_t pr = base + size_t(j) * kBlock;
+            if (pr < npairs) {
+                if constexpr (CX != 0) rx[j] = nt_load(reinterpret_cast<const typename raw_pair<CX>::type*>(bx) + pr);
+                if constexpr (CY != 0) ry[j] = nt_load(reinterpret_cast<const typename raw_pair<CY>::type*>(by) + pr);
+                if constexpr (CZ != 0) rz[j] = nt_load(reinterpret_cast<const typename raw_pair<CZ>::type*>(bz) + pr);
+                if constexpr (CW != 0) rw[j] = nt_load(reinterpret_cast<const typename raw_pair<CW>::type*>(bw) + pr);
+            }
         }
     }
     double vx[NC], vy[NC], o[NC];

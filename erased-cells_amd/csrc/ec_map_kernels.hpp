@@ -20,11 +20,15 @@ namespace ecd {
 // Fn interface:
 //   static constexpr int CPL;            cells per lane-group
 //   typename In;                         what load() returns
-//   In   load(size_t g) const;           loads for group g (cells [g*CPL, g*CPL+CPL))
+//   template <bool NT0, bool NT1> In load(size_t g) const;   loads for group g (cells [g*CPL, g*CPL+CPL)); NT0 / NT1:
+//                                        non-temporal (true) or default cache policy for the Fn's first / second
+//                                        input stream (a Fn with one input ignores NT1, one with none both)
 //   void store(size_t g, const In&) const;  compute + store for group g
 //   void cell(size_t i) const;           one cell, any alignment
+// `cacheable`: the launch's load policy (cache_plan, ec_runtime.hpp; policy_arms, ec_device.hpp) — bit 0 / bit 1 = the
+// first / second input stream fits the Infinity Cache and is loaded with the default policy (policy_arms, ec_device.hpp).
 template <typename Fn, int U>
-__global__ __launch_bounds__(kBlock) void k_map(Fn fn, size_t n) {
+__global__ __launch_bounds__(kBlock) void k_map(Fn fn, size_t n, unsigned cacheable) {
     using In = typename Fn::In;
     constexpr size_t CPL = Fn::CPL;
     const size_t ngroups = n / CPL;
@@ -33,15 +37,19 @@ __global__ __launch_bounds__(kBlock) void k_map(Fn fn, size_t n) {
     const size_t base = tile * TILE + threadIdx.x;
     if (tile * TILE + TILE <= ngroups) {
         In x[U];
+        constexpr int kStreams = (Fn::kIn0 != 0) + (Fn::kIn1 != 0);  // input streams of the Fn (a second one only after a first)
+        policy_arms<kStreams>(cacheable, [&](auto bits) {
+            constexpr unsigned B = decltype(bits)::value;
 #pragma unroll
-        for (int j = 0; j < U; ++j) x[j] = fn.load(base + size_t(j) * kBlock);
+            for (int j = 0; j < U; ++j) x[j] = fn.template load<!(B & 1u), !(B & 2u)>(base + size_t(j) * kBlock);
+        });
 #pragma unroll
         for (int j = 0; j < U; ++j) fn.store(base + size_t(j) * kBlock, x[j]);
     } else {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const size_t g = base + size_t(j) * kBlock;
-            if (g < ngroups) fn.store(g, fn.load(g));
+            if (g < ngroups) fn.store(g, fn.template load<true, true>(g));
         }
     }
     if (blockIdx.x == 0)
@@ -62,11 +70,13 @@ struct max_of { static constexpr int value = A > B ? A : B; };
 template <typename S, typename D>
 struct ConvertFn {
     static constexpr int CPL = 16 / max_of<sizeof(S), sizeof(D)>::value;
+    static constexpr size_t kIn0 = sizeof(S), kIn1 = 0;  // bytes per cell of the first / second input stream (load policy)
     using DV = vec<D, CPL>;
     using In = cells<S, CPL>;  // 1-byte sources travel as words: their loads keep `nt` (ec_device.hpp)
     const S* __restrict__ src;
     D* __restrict__ dst;
-    __device__ __forceinline__ In load(size_t g) const { return load_cells<true, S, CPL>(src + g * CPL); }
+    template <bool NT0, bool NT1>
+    __device__ __forceinline__ In load(size_t g) const { return load_cells<NT0, S, CPL>(src + g * CPL); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         if constexpr (sizeof(S) == 1) {
             DV o;
@@ -107,11 +117,13 @@ template <typename T>
 struct NegFn {
     using O = typename NegOut<T>::type;
     static constexpr int CPL = 16 / max_of<sizeof(T), sizeof(O)>::value;
+    static constexpr size_t kIn0 = sizeof(T), kIn1 = 0;
     using DV = vec<O, CPL>;
     using In = cells<T, CPL>;
     const T* __restrict__ src;
     O* __restrict__ dst;
-    __device__ __forceinline__ In load(size_t g) const { return load_cells<true, T, CPL>(src + g * CPL); }
+    template <bool NT0, bool NT1>
+    __device__ __forceinline__ In load(size_t g) const { return load_cells<NT0, T, CPL>(src + g * CPL); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         DV o;
 #pragma unroll
@@ -125,10 +137,12 @@ struct NegFn {
 template <typename W>
 struct FillFn {
     static constexpr int CPL = 16 / sizeof(W);
+    static constexpr size_t kIn0 = 0, kIn1 = 0;
     using DV = vec<W, CPL>;
     struct In {};
     W* __restrict__ dst;
     W value;
+    template <bool NT0, bool NT1>
     __device__ __forceinline__ In load(size_t) const { return In{}; }
     __device__ __forceinline__ void store(size_t g, const In&) const {
         DV o;
@@ -145,12 +159,14 @@ struct FillFn {
 template <typename W>
 struct MaskFromNodataFn {
     static constexpr int CPL = 16 / sizeof(W);
+    static constexpr size_t kIn0 = sizeof(W), kIn1 = 0;
     using MV = vec<uint8_t, CPL>;
     using In = cells<W, CPL>;
     const W* __restrict__ src;
     uint8_t* __restrict__ mask;
     W nd;
-    __device__ __forceinline__ In load(size_t g) const { return load_cells<true, W, CPL>(src + g * CPL); }
+    template <bool NT0, bool NT1>
+    __device__ __forceinline__ In load(size_t g) const { return load_cells<NT0, W, CPL>(src + g * CPL); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         MV m;
 #pragma unroll
@@ -164,14 +180,16 @@ struct MaskFromNodataFn {
 template <typename W>
 struct MaskSelectFn {
     static constexpr int CPL = 16 / sizeof(W);
+    static constexpr size_t kIn0 = sizeof(W), kIn1 = 1;
     using SV = vec<W, CPL>;
     struct In { cells<W, CPL> x; cells<uint8_t, CPL> m; };  // the mask bytes as words (ec_device.hpp)
     const W* __restrict__ src;
     const uint8_t* __restrict__ mask;
     W* __restrict__ dst;
     W nd;
+    template <bool NT0, bool NT1>
     __device__ __forceinline__ In load(size_t g) const {
-        return In{load_cells<true, W, CPL>(src + g * CPL), load_cells<true, uint8_t, CPL>(mask + g * CPL)};
+        return In{load_cells<NT0, W, CPL>(src + g * CPL), load_cells<NT1, uint8_t, CPL>(mask + g * CPL)};
     }
     __device__ __forceinline__ void store(size_t g, const In& in) const {
         SV o;
@@ -189,15 +207,16 @@ struct MaskSelectFn {
 template <int KIND>  // 0 and, 1 or
 struct MaskBin {
     static constexpr int CPL = 16;
+    static constexpr size_t kIn0 = 1, kIn1 = 1;
     struct In { u32x4 a, b; };
     // no __restrict__: the owned forms run in place (out == l; BitAnd/BitOr for Mask, mask.rs:118-127,142-151).
     // Every lane loads a group and stores the same group, so aliasing is well defined without it.
     const uint8_t* l;
     const uint8_t* r;
     uint8_t* out;
+    template <bool NT0, bool NT1>
     __device__ __forceinline__ In load(size_t g) const {
-        return In{nt_load(reinterpret_cast<const u32x4*>(l) + g),
-                  nt_load(reinterpret_cast<const u32x4*>(r) + g)};
+        return In{load_vec<NT0>(reinterpret_cast<const u32x4*>(l) + g), load_vec<NT1>(reinterpret_cast<const u32x4*>(r) + g)};
     }
     __device__ __forceinline__ void store(size_t g, const In& in) const {
         nt_store(KIND == 0 ? (in.a & in.b) : (in.a | in.b), reinterpret_cast<u32x4*>(out) + g);
@@ -210,10 +229,12 @@ struct MaskBin {
 
 struct MaskNot {
     static constexpr int CPL = 16;
+    static constexpr size_t kIn0 = 1, kIn1 = 0;
     using In = u32x4;
     const uint8_t* m;  // may alias out (Not for Mask, mask.rs:103-109)
     uint8_t* out;
-    __device__ __forceinline__ In load(size_t g) const { return nt_load(reinterpret_cast<const u32x4*>(m) + g); }
+    template <bool NT0, bool NT1>
+    __device__ __forceinline__ In load(size_t g) const { return load_vec<NT0>(reinterpret_cast<const u32x4*>(m) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
         nt_store(x ^ 0x01010101u, reinterpret_cast<u32x4*>(out) + g);
     }
@@ -224,6 +245,7 @@ struct MaskNot {
 template <typename T>
 struct SynthFn {
     static constexpr int CPL = 16 / sizeof(T);
+    static constexpr size_t kIn0 = 0, kIn1 = 0;
     using DV = vec<T, CPL>;
     struct In {};
     T* __restrict__ dst;
@@ -234,6 +256,7 @@ struct SynthFn {
         if constexpr (is_fp<T>::value) return static_cast<T>(lo + width * (double(h >> 11) * 0x1.0p-53));
         else return static_cast<T>(uint64_t(lo) + h % span);
     }
+    template <bool NT0, bool NT1>
     __device__ __forceinline__ In load(size_t) const { return In{}; }
     __device__ __forceinline__ void store(size_t g, const In&) const {
         DV o;
@@ -246,12 +269,14 @@ struct SynthFn {
 
 struct SynthMaskFn {
     static constexpr int CPL = 16;
+    static constexpr size_t kIn0 = 0, kIn1 = 0;
     using DV = vec<uint8_t, 16>;
     struct In {};
     uint8_t* __restrict__ dst;
     uint64_t seed, base;
     uint32_t pct;
     __device__ __forceinline__ uint8_t gen(size_t i) const { return splitmix64(seed ^ (base + i)) % 100 >= pct; }
+    template <bool NT0, bool NT1>
     __device__ __forceinline__ In load(size_t) const { return In{}; }
     __device__ __forceinline__ void store(size_t g, const In&) const {
         DV o;

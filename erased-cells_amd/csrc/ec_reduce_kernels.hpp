@@ -142,7 +142,11 @@ __global__ __launch_bounds__(BLOCK) void k_min_max_partials(const T* __restrict_
     // keys2_if_single != nullptr (only with a one-workgroup grid): this workgroup's fold IS the result, so it writes
     // {~key(min), key(max)} itself and the finalize launch is skipped — half the latency for small buffers.
     // `head` leading cells (reduce_head(), ec_runtime.hpp) are folded one by one by workgroup 0 so that the
-    // 16-byte loads of the rest start 16-byte aligned: a window at an odd u16 offset otherwise reads 27 % slower
+    // 16-byte loads of the rest start 16-byte aligned: a window at an odd u16 offset otherwise reads 27 % slower.
+    // Bits 8.. of `head`: the launch's load policy — bit 8 = the cells, bit 9 = the mask fit the Infinity Cache and are
+    // loaded with the default cache policy instead of nt (cache_plan, ec_runtime.hpp; policy_arms, ec_device.hpp).
+    const unsigned cacheable = head >> 8;
+    head &= 0xffu;
     p += head;
     if constexpr (MASKED) mask += head;
     n -= head;
@@ -186,11 +190,14 @@ __global__ __launch_bounds__(BLOCK) void k_min_max_partials(const T* __restrict_
         if (tile * TILE + TILE <= ngroups) {
             TV x[U];
             MV m[U] = {};
+            policy_arms<(MASKED ? 2 : 1)>(cacheable, [&](auto bits) {  // bit 0: the cells, bit 1: the mask (ec_device.hpp)
+                constexpr unsigned B = decltype(bits)::value;
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                x[j] = load_cells<true, T, CPL>(p + (base + size_t(j) * BLOCK) * CPL);
-                if constexpr (MASKED) m[j] = load_cells<true, uint8_t, CPL>(mask + (base + size_t(j) * BLOCK) * CPL);
-            }
+                for (int j = 0; j < U; ++j) {
+                    x[j] = load_cells<!(B & 1u), T, CPL>(p + (base + size_t(j) * BLOCK) * CPL);
+                    if constexpr (MASKED) m[j] = load_cells<!(B & 2u), uint8_t, CPL>(mask + (base + size_t(j) * BLOCK) * CPL);
+                }
+            });
 #pragma unroll
             for (int j = 0; j < U; ++j) fold(x[j], m[j]);
         } else {
@@ -340,6 +347,8 @@ __global__ __launch_bounds__(kRBlock) void k_first_diff_partials(const W* __rest
     constexpr int CPL = 16 / sizeof(W);
     using WV = cells<W, CPL>;
     uint64_t first = ~0ull;
+    const unsigned cacheable = head >> 8;  // load policy of the launch: bit 8 = l, bit 9 = r (see k_min_max_partials)
+    head &= 0xffu;
     if (aligned) {
         // `head` leading cells are compared singly by workgroup 0 (see k_min_max_partials); indices stay absolute
         if (blockIdx.x == 0)
@@ -364,11 +373,14 @@ __global__ __launch_bounds__(kRBlock) void k_first_diff_partials(const W* __rest
             };
             if (tile * TILE + TILE <= ngroups) {  // full tile: all 2 x U loads in flight before the first compare
                 WV a[U], b[U];
+                policy_arms<2>(cacheable, [&](auto bits) {
+                    constexpr unsigned B = decltype(bits)::value;
 #pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    a[j] = load_cells<true, W, CPL>(l + (base + size_t(j) * kRBlock) * CPL);
-                    b[j] = load_cells<true, W, CPL>(r + (base + size_t(j) * kRBlock) * CPL);
-                }
+                    for (int j = 0; j < U; ++j) {
+                        a[j] = load_cells<!(B & 1u), W, CPL>(l + (base + size_t(j) * kRBlock) * CPL);
+                        b[j] = load_cells<!(B & 2u), W, CPL>(r + (base + size_t(j) * kRBlock) * CPL);
+                    }
+                });
 #pragma unroll
                 for (int j = 0; j < U; ++j) compare(base + size_t(j) * kRBlock, a[j], b[j]);
             } else {
@@ -434,6 +446,8 @@ __global__ __launch_bounds__(kRBlock) void k_mask_count_partials(const uint8_t* 
                                                                 uint64_t* __restrict__ counts2_if_single) {
     const uint64_t n_total = n;
     uint64_t cnt = 0;
+    const bool cacheable = ((head >> 8) & 1u) != 0;  // load policy of the launch (see k_min_max_partials)
+    head &= 0xffu;
     if (aligned) {
         if (blockIdx.x == 0)  // peeled leading cells (see k_min_max_partials)
             for (unsigned h = threadIdx.x; h < head; h += kRBlock) cnt += ld_cell(m + h) & 1;
@@ -452,8 +466,10 @@ __global__ __launch_bounds__(kRBlock) void k_mask_count_partials(const uint8_t* 
             };
             if (tile * TILE + TILE <= ngroups) {  // full tile: every load in flight before the first popcount
                 u32x4 x[U];
+                policy_arms<1>(cacheable ? 1u : 0u, [&](auto bits) {
 #pragma unroll
-                for (int j = 0; j < U; ++j) x[j] = nt_load(mv + base + size_t(j) * kRBlock);
+                    for (int j = 0; j < U; ++j) x[j] = load_vec<!(decltype(bits)::value & 1u)>(mv + base + size_t(j) * kRBlock);
+                });
 #pragma unroll
                 for (int j = 0; j < U; ++j) c32 += pop16(x[j]);
             } else {

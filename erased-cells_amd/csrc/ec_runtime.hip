@@ -429,6 +429,7 @@ extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     else if (!std::strcmp(key, "peel")) g_tuning.peel = static_cast<int>(value);
     else if (!std::strcmp(key, "unaligned_vector")) g_tuning.unaligned_vector = value != 0;
     else if (!std::strcmp(key, "fused_mixed")) g_tuning.fused_mixed = static_cast<int>(value);
+    else if (!std::strcmp(key, "mall_mb")) g_tuning.mall_mb = value < 0 ? 0 : value;
     else if (!std::strcmp(key, "inject_shard_failure")) g_tuning.inject_shard_failure = static_cast<int>(value);
     else if (!std::strcmp(key, "pool_keep_mb")) {
         g_tuning.pool_keep_mb = value < 0 ? 0 : value;

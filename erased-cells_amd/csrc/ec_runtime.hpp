@@ -41,6 +41,8 @@ struct Tuning {
     std::atomic<int> unaligned_vector{1};  // 1 = vector kernels at any cell offset (gfx950 unaligned global access);
                                            // 0 = pointers that are not 16-byte aligned run the cell-wise kernels
     std::atomic<int> fused_mixed{1};       // 1 = one-pass typed-load kernels for fused chains over mixed cell types; 0 = convert, then fuse
+    std::atomic<int64_t> mall_mb{256};     // Infinity Cache budget of cache_plan(): operand streams that fit it together are loaded with
+                                           // the default cache policy, all others non-temporal; 0 = every stream non-temporal
     std::atomic<int> inject_shard_failure{0};  // test hook: shard index + 1 whose NEXT fire-and-forget job of a shard group reports
                                                // EC_ERR_HIP instead of launching (exercises the deferred-error path); 0 = off
     std::atomic<int64_t> pool_keep_mb{32768};  // release threshold of the library's stream-ordered pool (per device)
@@ -82,6 +84,30 @@ inline unsigned peel_head(const void* l, size_t lsize, const void* r, size_t rsi
     const unsigned c0 = peel_cost(l, lsize, 0) + (r ? peel_cost(r, rsize, 0) : 0);
     const unsigned c1 = peel_cost(l, lsize, 1) + (r ? peel_cost(r, rsize, 1) : 0);
     return c1 < c0 ? 1u : 0u;
+}
+
+// Load policy of a launch (policy_arms(), ec_device.hpp): bit k set = operand stream k is loaded with the default cache
+// policy because it may still be — or is worth leaving — in the 256 MiB Infinity Cache; clear = non-temporal.  Streams
+// are admitted smallest first while they fit the budget TOGETHER (two 256 MiB operands would only evict each other); a
+// stream bigger than the cache is always streamed.  The figures behind the rule (MI355X, 16384² cells, profiles/r03/
+// tune_nt_width_rotating.log): the u8 ÷ u16 divide with its 256 MiB u8 operand cacheable runs at 0.856 of the HBM peak
+// when that operand was touched by the previous launch and 0.792 when it was not; with every load nt, 0.80 either way.
+// Big streams want nt: a 2 GiB read-only stream reaches 0.865 nt against 0.76 cacheable.
+inline unsigned cache_plan(const size_t* bytes, int n) {
+    const size_t budget = static_cast<size_t>(tuning().mall_mb.load()) << 20;
+    unsigned plan = 0;
+    size_t used = 0;
+    bool taken[8] = {false, false, false, false, false, false, false, false};
+    for (int round = 0; round < n && n <= 8; ++round) {
+        int best = -1;
+        for (int k = 0; k < n; ++k)
+            if (!taken[k] && bytes[k] > 0 && (best < 0 || bytes[k] < bytes[best])) best = k;
+        if (best < 0 || used + bytes[best] > budget) break;
+        taken[best] = true;
+        used += bytes[best];
+        plan |= 1u << best;
+    }
+    return plan;
 }
 
 // Leading cells a reduction peels so that its 16-byte loads start 16-byte aligned (0 when the window is shorter).

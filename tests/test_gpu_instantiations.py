@@ -1,8 +1,8 @@
 """Every kernel instantiation the library ships is executed at least once against the oracle.
 
 The parity tests walk the default path over all type pairs; this file sweeps the remaining template
-instantiations — the LDS-staged variant, the masked kernels, all 800 fused (type x op-triple) kernels, the
-map kernels at every tile depth and the cell-wise comparison path — on small inputs.  (Which kernels a run
+instantiations — the LDS-staged variant, the masked kernels, all 624 fused kernels (one per quadruple of operand
+load classes) under every op triple and cell kind, the map kernels at every tile depth and the cell-wise comparison path — on small inputs.  (Which kernels a run
 executed can be listed with `rocprofv3 --kernel-trace --stats -- python3 -m pytest tests -m gpu`.)
 """
 import ctypes as C
@@ -97,7 +97,8 @@ def _oracle_chain(o1, hx, hy, o2, hz, o3=None, hw=None):
 
 @pytest.mark.parametrize("ct", range(NT))
 def test_fused_every_op_triple(ec, pool, ct):
-    """All 80 (o1, o2, o3) instantiations of k_fused_same<T> for each cell type: bit-identical to the eager HIP chain,
+    """All 80 (o1, o2, o3) op triples on operands of one cell type (k_fused_any<c,c,0,0> with the aliases of this
+    call; the op arms are launch-uniform switches): bit-identical to the eager HIP chain,
     and to the ORACLE's chain under the same rule as test_binop_all_pairs_bit_exact (NaNs bit for bit, except cells
     where both operands of a commutative step are NaN)."""
     host, dev, _, _ = pool
@@ -287,8 +288,6 @@ def test_fused_any_every_class_kernel(ec, pool, cx):
     """All 625 k_fused_any<CX,CY,CZ,CW> kernels (624 reachable: at least one operand is a buffer), four-operand chains
     for every class quadruple and three-operand chains for every triple, cell kinds, aliases, scalars and op triples
     rotating: against the oracle's chain under the single-op NaN rule; nothing is allocated."""
-    L = ec.lib()
-    L.ec_tune_set(b"fused_mixed", 2)  # same-type operand sets go through k_fused_any too
     try:
         tick = 0
         for cy in _CLASSES:
@@ -316,28 +315,7 @@ def test_fused_any_every_class_kernel(ec, pool, cx):
                         except AssertionError as e:
                             raise AssertionError(f"classes {classes} nops {nops} ops {(o1, o2, o3)}: {e}") from None
     finally:
-        L.ec_tune_set(b"fused_mixed", 1)
-
-
-@pytest.mark.parametrize("ct", range(NT))
-def test_fused_any_equals_the_specialised_kernels(ec, pool, ct):
-    """Same-type chains run k_fused_same by default; forced through k_fused_any (fused_mixed = 2) every op triple gives
-    the same bits — including the NDVI shape on ≤16-bit cells, which both evaluate with the 6-instruction divide."""
-    host, dev, _, _ = pool
-    L = ec.lib()
-    x, y, z = dev[ct].shard(0, N), dev[ct].shard(4, N), dev[ct].shard(2, N)
-    for o1 in OPS:
-        for o2 in OPS:
-            for o3 in OPS + [ec.fused.OP_NONE]:
-                args = (x, o1, y, o2, x, o3, y) if o3 != ec.fused.OP_NONE else (x, o1, y, o2, z)
-                try:
-                    L.ec_tune_set(b"fused_mixed", 1)
-                    a = ec.fused.expr(*args).to_numpy()
-                    L.ec_tune_set(b"fused_mixed", 2)
-                    b = ec.fused.expr(*args).to_numpy()
-                finally:
-                    L.ec_tune_set(b"fused_mixed", 1)
-                assert np.array_equal(bits_of(a), bits_of(b)), (ct, o1, o2, o3)
+        pass
 
 
 def test_fused_three_and_four_cell_types_with_masks(ec, pool):
@@ -367,6 +345,52 @@ def test_fused_three_and_four_cell_types_with_masks(ec, pool):
             eo4, loose4 = _oracle_chain(o1, hs[0], hs[1], o2, hs[2], o3, np.full(n, 2.5))
             assert_f64_bits_equal(gm.buffer().to_numpy(), eo4, nan_by_class_where=loose4)
             assert np.array_equal(gm.mask().to_numpy(), hm[0] & hm[1] & hm[2])
+
+
+def test_every_kernel_family_with_every_load_non_temporal(ec, pool):
+    """The launch's load policy (cache_plan / policy_arms): the test-sized operands of this file all fit the Infinity Cache
+    budget, so every sweep above runs the default-policy arms; this one repeats the sweeps with the budget at 0 — the
+    nt arm of every kernel — and, for the two-stream kernels, with a budget that admits exactly the smaller operand
+    (the mixed arms)."""
+    L = ec.lib()
+    try:
+        for budget_mb in (0,):
+            L.ec_tune_set(b"mall_mb", budget_mb)
+            test_masked_binop_direct_every_pair(ec, pool)
+            test_map_kernels_every_instantiation(ec, pool, 2, 1, 0)
+            for cx in _CLASSES:
+                test_fused_any_every_class_kernel(ec, pool, cx)
+            test_fused_three_and_four_cell_types_with_masks(ec, pool)
+    finally:
+        L.ec_tune_set(b"mall_mb", 256)
+    # mixed arms: 3 MiB budget, operands of 1 / 2 / 4 / 8 MiB
+    from vectors import rand_cells, rand_mask
+    n = 1 << 20
+    try:
+        L.ec_tune_set(b"mall_mb", 3)
+        host = {ct: rand_cells(ct, n, 7100 + ct) for ct in (eco.U8, eco.U16, eco.F32, eco.F64)}
+        dev = {ct: ec.CellBuffer.from_vec(a) for ct, a in host.items()}
+        hm = [rand_mask(n, 7200 + k) for k in range(2)]
+        dm = [ec.Mask.new(x) for x in hm]
+        for lt, rt in ((eco.U8, eco.U16), (eco.U16, eco.U8), (eco.F64, eco.U8), (eco.U16, eco.F32), (eco.F32, eco.F64)):
+            for op in OPS:
+                exp = eco.f_binop(op, host[lt], host[rt])
+                assert_f64_bits_equal(dev[lt]._binop(op, dev[rt]).to_numpy(), exp, nan_by_class_where=_loose(op, host[lt], host[rt]))
+            got = ec.MaskedCellBuffer(dev[lt], dm[0])._binop(eco.MUL, ec.MaskedCellBuffer(dev[rt], dm[1]))
+            assert_f64_bits_equal(got.buffer().to_numpy(), eco.f_binop(eco.MUL, host[lt], host[rt]),
+                                  nan_by_class_where=_loose(eco.MUL, host[lt], host[rt]))
+            assert np.array_equal(got.mask().to_numpy(), hm[0] & hm[1])
+        got = ec.fused.expr(dev[eco.U8], eco.SUB, dev[eco.U16], eco.DIV, dev[eco.F32], eco.ADD, dev[eco.F64])
+        eo, loose = _oracle_chain(eco.SUB, host[eco.U8], host[eco.U16], eco.DIV, host[eco.F32], eco.ADD, host[eco.F64])
+        assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+        for ct in (eco.U8, eco.U16, eco.F32):
+            gm = ec.MaskedCellBuffer(dev[ct], dm[0]).min_max()
+            em = eco.f_min_max(host[ct], hm[0])
+            assert (gm[0].bits(), gm[1].bits()) == (em[0].bits(), em[1].bits())
+            sel = ec.MaskedCellBuffer(dev[ct], dm[1]).to_vec_with_nodata(ct, ec.NoData.default())
+            assert np.array_equal(bits_of(sel), bits_of(eco.f_mask_select(host[ct], hm[1], eco.nodata_value(eco.ND_DEFAULT, ct))))
+    finally:
+        L.ec_tune_set(b"mall_mb", 256)
 
 
 SMALL = {  # cell type -> (lowest, highest) cell value

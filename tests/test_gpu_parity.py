@@ -27,17 +27,22 @@ def ec():
     return ec
 
 
-@pytest.fixture(params=[(1, 1), (0, 1), (1, 2), (1, 0)],
-                ids=["default", "cellwise-when-unaligned", "peel-2-byte-operands-too", "no-peel"])
+@pytest.fixture(params=[(1, 1, 256), (0, 1, 256), (1, 2, 256), (1, 0, 256), (1, 1, 0)],
+                ids=["default", "cellwise-when-unaligned", "peel-2-byte-operands-too", "no-peel", "every-load-nt"])
 def ua(ec, request):
-    """Alternative paths for windows that are not 16-byte aligned; all must match the oracle.
-    unaligned_vector: vector kernels with unaligned global access (default) or, knob off, the cell-wise kernels.
-    peel: leading-cell peel of the binop/fused kernels for 1-byte operands (default), also 2-byte ones, or never."""
+    """Alternative paths; all must match the oracle.
+    unaligned_vector: vector kernels with unaligned global access (default) or, knob off, the cell-wise kernels for
+    windows that are not 16-byte aligned.
+    peel: leading-cell peel of the binop/fused kernels for 1-byte operands (default), also 2-byte ones, or never.
+    mall_mb: Infinity Cache budget of the launch's load policy — 256 (default: operands that fit are loaded with the
+    default cache policy; test-sized operands all do) or 0 (every load non-temporal): the two arms of every policy branch."""
     ec.lib().ec_tune_set(b"unaligned_vector", request.param[0])
     ec.lib().ec_tune_set(b"peel", request.param[1])
+    ec.lib().ec_tune_set(b"mall_mb", request.param[2])
     yield request.param
     ec.lib().ec_tune_set(b"unaligned_vector", 1)
     ec.lib().ec_tune_set(b"peel", 1)
+    ec.lib().ec_tune_set(b"mall_mb", 256)
 
 
 def _both_nan(l, r):

@@ -7,11 +7,16 @@ byte stream of the reductions went out as plain `global_load_*` (found by disass
 kernels now move 1-byte cells as unsigned words (`cells<T, N>`, ec_device.hpp); this tool keeps it that way.
 
 It compiles the given translation units of erased-cells_amd/csrc to gfx950 assembly (device side only, no GPU
-needed) and checks the invariant the kernels are written to: in a streaming kernel EVERY global load and EVERY global
-store of caller data carries `nt` — the full tiles, the guarded tail tiles and the single head / tail cells alike
-(`load_cells`, `ld_cell` / `st_cell`, ec_device.hpp).  Exempt by name: the cell-wise comparison kernels and the
-one-workgroup finalize kernels (they read a few KB of partials that were just written: cached on purpose); in the
-reduction kernels the STORES are exempt (per-workgroup partials and the result words, re-read at once).
+needed) and checks the invariant the kernels are written to.  In a streaming kernel
+  * every global STORE of caller data carries `nt`;
+  * every global LOAD carries `nt` — the full tiles, the guarded tail tiles and the single head / tail cells alike
+    (`load_cells`, `ld_cell` / `st_cell`, ec_device.hpp) — EXCEPT the deliberate default-policy twin of a full tile's
+    operand loads: the host may mark an operand stream that fits the Infinity Cache "cacheable" for a launch
+    (`cache_plan`, ec_runtime.hpp), and `load_stream` then takes a wave-uniform branch to the same loads without `nt`.
+    So per kernel and per load opcode the plain loads may not outnumber the nt loads (each plain load has its nt twin).
+Exempt by name: the cell-wise comparison kernels and the one-workgroup finalize kernels (they read a few KB of partials
+that were just written: cached on purpose); in the reduction kernels the STORES are exempt (per-workgroup partials and
+the result words, re-read at once).
 
     python tools/isa_audit.py                       # the default TU list, prints a summary, exit 1 on a finding
     python tools/isa_audit.py ec_binop_div.hip -v   # per kernel
@@ -27,7 +32,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "erased-cells_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-DEFAULT_TUS = ["ec_abi.hip", "ec_binop_div.hip", "ec_fused_div.hip", "ec_fusedany_c1.hip"]
+DEFAULT_TUS = ["ec_abi.hip", "ec_binop_div.hip", "ec_fusedany_c1.hip", "ec_fusedany_c4.hip"]
 SKIP = re.compile(r"cellwise|finalize")
 MEM = re.compile(r"^\s+((?:global|buffer)_(load|store)_\w+)\s+(.*)$")
 KERNEL = re.compile(r"^(_Z\S+):")
@@ -66,9 +71,20 @@ def audit(asm_path):
                 continue
             acc = [a for a in accesses if a[0] == kind]
             audited[kernel] += len(acc)
-            bad = [a for a in acc if not a[1]]
-            if bad:
-                findings.setdefault(kernel, []).append((kind, len(acc), len(bad), bad[0][2]))
+            if kind == "store":
+                bad = [a for a in acc if not a[1]]
+                if bad:
+                    findings.setdefault(kernel, []).append((kind, len(acc), len(bad), bad[0][2]))
+                continue
+            by_op = collections.defaultdict(lambda: [0, 0, None])  # opcode -> [nt, plain, example of a plain one]
+            for a in acc:
+                op = a[2].split()[0]
+                by_op[op][0 if a[1] else 1] += 1
+                if not a[1]:
+                    by_op[op][2] = a[2]
+            for op, (n_nt, n_plain, ex) in by_op.items():
+                if n_plain > n_nt:
+                    findings.setdefault(kernel, []).append((f"load ({op}: {n_nt} nt)", n_nt + n_plain, n_plain, ex))
     return findings, audited
 
 

@@ -4,7 +4,7 @@
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03pmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-COMMON="--steps 5 --warmup 1 --ramp 0 --no-cpu-baseline --no-reference-streams"
+COMMON="--steps 5 --warmup 1 --ramp 0 --no-cpu-baseline --no-reference-streams --no-fresh-inputs"
 run() {  # name, counters, bench flags
   local name=$1 ctrs=$2; shift 2
   rocprofv3 --pmc $ctrs --kernel-trace -d $O/$name --output-format csv -- python3 /root/repo/bench.py $COMMON "$@" > $O/$name.json 2> $O/$name.err || { tail -5 $O/$name.err; return 1; }

@@ -1,8 +1,9 @@
 // tune_fused_any.hip — k_fused_any (load classes compile-time, kinds and ops launch-uniform: ec_fused_any.hpp) against the
 // kernels specialised per cell type and op triple (k_fused_same, k_fused_mixed), on the same buffers, randomised
 // interleaved rounds, checksummed outputs (dev tool, round 3).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -ffp-contract=off -Iinclude -Ierased-cells_amd/csrc \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -ffp-contract=off -Iinclude -Ierased-cells_amd/csrc -Itools \
 //         tools/tune_fused_any.hip -o tools/tune_fused_any && ./tools/tune_fused_any [side] [rounds]
+//   (-DEC_FUSED_U=N forces one tile depth on every kernel, the legacy ones included)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -14,7 +15,7 @@
 #include <vector>
 
 #include "ec_fused_any.hpp"
-#include "ec_fused_mixed.hpp"
+#include "legacy_fused_kernels.hpp"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 using namespace ecd;
 
@@ -82,7 +83,8 @@ int main(int argc, char** argv) {
     k_fill<<<2048, 256>>>(a, b, c, d, e, u8, m0, m1, m2, n);
     CK(hipDeviceSynchronize());
     auto grid_u = [&](int u) { return unsigned((n / 2 + 256 * size_t(u) - 1) / (256 * size_t(u))); };
-    auto grid_of = [&](size_t cell_bytes) { return grid_u(fused_u(cell_bytes)); };
+    auto grid_of = [&](size_t cell_bytes) { return grid_u(fused_u(cell_bytes)); };            // k_fused_any
+    auto lgrid_of = [&](size_t cell_bytes) { return grid_u(legacy_fused_u(cell_bytes)); };   // the legacy kernels' own depth
 
     std::vector<Variant> vs;
     // ---- NDVI u16 (12 B/cell): two u16 streams, z = x, w = y
@@ -90,7 +92,7 @@ int main(int argc, char** argv) {
         const void* p[4] = {a, reinterpret_cast<uint16_t*>(b), a, reinterpret_cast<uint16_t*>(b)};
         const int dt[4] = {EC_U16, EC_U16, EC_U16, EC_U16};
         FusedArgs fa = make(4, p, dt, EC_SUB, EC_DIV, EC_ADD);
-        vs.push_back({"NDVI u16            k_fused_same", [=] { k_fused_same<uint16_t, EC_SUB, EC_DIV, EC_ADD><<<grid_of(2), 256>>>(fa, out, nullptr, n); }, 12, 0, {}});
+        vs.push_back({"NDVI u16            k_fused_same", [=] { k_fused_same<uint16_t, EC_SUB, EC_DIV, EC_ADD><<<lgrid_of(2), 256>>>(fa, out, nullptr, n); }, 12, 0, {}});
         FusedArgs fb = fa; fb.small = 1;
         vs.push_back({"NDVI u16            k_fused_any<2,2,0,0>", [=] { k_fused_any<2, 2, 0, 0><<<grid_of(2), 256>>>(fb, out, nullptr, n); }, 12, 0, {}});
         FusedArgs fc = fa; fc.small = 0;
@@ -101,7 +103,7 @@ int main(int argc, char** argv) {
         const void* p[4] = {a, b, a, b};
         const int dt[4] = {EC_U16, EC_F32, EC_U16, EC_F32};
         FusedArgs fa = make(4, p, dt, EC_SUB, EC_DIV, EC_ADD);
-        vs.push_back({"NDVI u16+f32        k_fused_mixed", [=] { k_fused_mixed<uint16_t, float, kPatABAB, EC_SUB, EC_DIV, EC_ADD><<<grid_of(2), 256>>>(fa, out, nullptr, n); }, 14, 1, {}});
+        vs.push_back({"NDVI u16+f32        k_fused_mixed", [=] { k_fused_mixed<uint16_t, float, kPatABAB, EC_SUB, EC_DIV, EC_ADD><<<lgrid_of(2), 256>>>(fa, out, nullptr, n); }, 14, 1, {}});
         vs.push_back({"NDVI u16+f32        k_fused_any<2,4,0,0>", [=] { k_fused_any<2, 4, 0, 0><<<grid_of(2), 256>>>(fa, out, nullptr, n); }, 14, 1, {}});
     }
     // ---- config 3: (c + d) * b on f32 with three masks (24 B/cell)
@@ -110,7 +112,7 @@ int main(int argc, char** argv) {
         const int dt[4] = {EC_F32, EC_F32, EC_F32, EC_F32};
         FusedArgs fa = make(3, p, dt, EC_ADD, EC_MUL, kOpNone);
         fa.m[0] = m0; fa.m[1] = m1; fa.m[2] = m2; fa.nmask = 3;
-        vs.push_back({"config 3 f32+masks  k_fused_same", [=] { k_fused_same<float, EC_ADD, EC_MUL, kOpNone><<<grid_of(4), 256>>>(fa, out, om, n); }, 24, 2, {}});
+        vs.push_back({"config 3 f32+masks  k_fused_same", [=] { k_fused_same<float, EC_ADD, EC_MUL, kOpNone><<<lgrid_of(4), 256>>>(fa, out, om, n); }, 24, 2, {}});
         vs.push_back({"config 3 f32+masks  k_fused_any<4,4,4,0>", [=] { k_fused_any<4, 4, 4, 0><<<grid_of(4), 256>>>(fa, out, om, n); }, 24, 2, {}});
     }
     // ---- (c + d) * e : f32, f32, f64 (24 B/cell)
@@ -118,7 +120,7 @@ int main(int argc, char** argv) {
         const void* p[4] = {c, d, e, nullptr};
         const int dt[4] = {EC_F32, EC_F32, EC_F64, EC_F64};
         FusedArgs fa = make(3, p, dt, EC_ADD, EC_MUL, kOpNone);
-        vs.push_back({"(f32+f32)*f64       k_fused_mixed AAB", [=] { k_fused_mixed<float, double, kPatAAB, EC_ADD, EC_MUL, kOpNone><<<grid_of(4), 256>>>(fa, out, nullptr, n); }, 24, 3, {}});
+        vs.push_back({"(f32+f32)*f64       k_fused_mixed AAB", [=] { k_fused_mixed<float, double, kPatAAB, EC_ADD, EC_MUL, kOpNone><<<lgrid_of(4), 256>>>(fa, out, nullptr, n); }, 24, 3, {}});
         vs.push_back({"(f32+f32)*f64       k_fused_any<4,4,8,0>", [=] { k_fused_any<4, 4, 8, 0><<<grid_of(4), 256>>>(fa, out, nullptr, n); }, 24, 3, {}});
     }
     // ---- mixes rounds 1-2 ran as convert-then-fuse
