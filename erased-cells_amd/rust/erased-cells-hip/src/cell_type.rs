@@ -1,15 +1,17 @@
-//! `CellType` (src/ctype.rs:11-180 of the reference) and `CellEncoding` (src/encoding.rs:9-40): the ten cell encodings
-//! and the primitives that carry them.  `self as u8` IS the ABI dtype
-//! code; the lattice (`union`, `can_fit_into`, limits) is answered by the library's host-side table, the same
-//! one its kernel dispatch uses.
+//! [`CellType`]: the ten cell encodings.
+//!
+//! PROVENANCE.  The enum (variant names and order) and the method signatures are the reference's public surface
+//! (erased-cells 0.1.1, src/ctype.rs:11-180, MIT License, Copyright (c) 2023 Astraea, Inc.); the bodies are this crate's:
+//! `self as u8` IS the ABI dtype code, and the lattice (`union`, `can_fit_into`, sizes, limits) is answered by the
+//! library's host-side table — the same one its kernel dispatch uses — instead of being restated here.
 use crate::error::Error;
 use crate::ffi::*;
 use crate::CellValue;
-use num_traits::{One, Zero};
 use std::fmt::{Debug, Display, Formatter};
 use std::str::FromStr;
 
-/// Cell-type variants, in the order of `with_ct!`.
+// api-surface(src/ctype.rs:9-20): the enum — variant names and order (discriminants written out: they are the ABI's dtype codes)
+/// The encoding of a cell: one of the ten Rust primitives a cell can be.
 #[derive(Debug, Copy, Clone, PartialEq, Eq, PartialOrd, Ord, Hash)]
 #[repr(u8)]
 pub enum CellType {
@@ -24,13 +26,14 @@ pub enum CellType {
     Float32 = 8,
     Float64 = 9,
 }
+// end api-surface
 
 const ALL: [CellType; 10] = [
     CellType::UInt8, CellType::UInt16, CellType::UInt32, CellType::UInt64, CellType::Int8, CellType::Int16,
     CellType::Int32, CellType::Int64, CellType::Float32, CellType::Float64,
 ];
 
-/// `Display` is the same as `Debug`.
+/// Prints the variant name, as `Debug` does.
 impl Display for CellType {
     fn fmt(&self, f: &mut Formatter<'_>) -> std::fmt::Result {
         Debug::fmt(self, f)
@@ -51,102 +54,58 @@ impl CellType {
         ALL[c as usize]
     }
 
-    /// Get an iterator over all the valid enumeration values.
+    /// The ten variants in discriminant order.
     pub fn iter() -> impl Iterator<Item = CellType> {
         ALL.into_iter()
     }
 
-    /// Determine if `self` is integral or floating-point.
+    /// `false` for the two float types.
     pub fn is_integral(&self) -> bool {
         !matches!(self, CellType::Float32 | CellType::Float64)
     }
 
-    /// Determine if `self` is signed or unsigned.
+    /// `false` for the four unsigned integer types (floats are signed).
     pub fn is_signed(&self) -> bool {
         !matches!(self, CellType::UInt8 | CellType::UInt16 | CellType::UInt32 | CellType::UInt64)
     }
 
-    /// Number of bytes needed to encode `self`.
+    /// Bytes per cell.
     pub fn size_of(&self) -> usize {
         unsafe { ec_size_of(*self as u8) }
     }
 
-    /// Select the `CellType` that can numerically contain both `self` and `other`.
+    /// The narrowest cell type that represents every value of both `self` and `other` (where none does — e.g. `u64` with
+    /// a signed type — `Float64`).
     pub fn union(self, other: Self) -> Self {
         Self::from_code(unsafe { ec_union(self as u8, other as u8) })
     }
 
-    /// Determine of `self` can fit within `other`.
+    /// Does `other` represent every value of `self`?  (`self.union(other) == other`.)  This is what `convert` checks.
     pub fn can_fit_into(self, other: Self) -> bool {
         unsafe { ec_can_fit_into(self as u8, other as u8) != 0 }
     }
 
-    /// Construct the zero value for a variant.
+    /// 0 as a value of this cell type.
     pub fn zero(&self) -> CellValue {
         CellValue::small(*self, 0)
     }
 
-    /// Construct the one value for a variant.
+    /// 1 as a value of this cell type.
     pub fn one(&self) -> CellValue {
         CellValue::small(*self, 1)
     }
 
-    /// Determine the minimum value that can be represented by `self`.
+    /// The least value of the primitive (`T::MIN`: finite for floats).
     pub fn min_value(&self) -> CellValue {
         let mut v = CellValue::UInt8(0).to_ffi();
         unsafe { ec_min_value(*self as u8, &mut v) };
         CellValue::from_ffi(&v)
     }
 
-    /// Determine the maximum value that can be represented by `self`.
+    /// The greatest value of the primitive (`T::MAX`: finite for floats).
     pub fn max_value(&self) -> CellValue {
         let mut v = CellValue::UInt8(0).to_ffi();
         unsafe { ec_max_value(*self as u8, &mut v) };
         CellValue::from_ffi(&v)
     }
 }
-
-/// Trait for marking Rust primitives as having a corresponding [`CellType`]: implemented for exactly the ten
-/// primitives a cell can hold (`u8` … `f64`); `isize`, `bool`, `u128` … are not cell encodings.
-pub trait CellEncoding: Copy + Debug + Default + Zero + One + PartialEq {
-    /// Returns the [`CellType`] covering `Self`.
-    fn cell_type() -> CellType;
-    /// Converts `self` into a [`CellValue`].
-    fn into_cell_value(self) -> CellValue;
-    /// Convert dynamic type to static type when logically known: `Some` only when `T` is exactly `Self` (equal cell
-    /// types mean the same primitive, so the value is copied bit for bit), `None` for every other pair — there is
-    /// no numeric conversion here, that is `CellValue::convert`'s job.
-    fn static_cast<T: CellEncoding + Sized>(value: T) -> Option<Self> {
-        (Self::cell_type() == T::cell_type()).then(|| {
-            debug_assert_eq!(std::mem::size_of::<T>(), std::mem::size_of::<Self>());
-            let mut same = Self::default();
-            unsafe {
-                std::ptr::copy_nonoverlapping(&value as *const T as *const u8, &mut same as *mut Self as *mut u8, std::mem::size_of::<Self>())
-            };
-            same
-        })
-    }
-}
-
-macro_rules! cell_encoding_of {
-    ($prim:ty => $ct:ident) => {
-        impl CellEncoding for $prim {
-            fn cell_type() -> CellType {
-                CellType::$ct
-            }
-            fn into_cell_value(self) -> CellValue {
-                CellValue::$ct(self)
-            }
-        }
-    };
-}
-cell_encoding_of!(u8 => UInt8);
-cell_encoding_of!(u16 => UInt16);
-cell_encoding_of!(u32 => UInt32);
-cell_encoding_of!(u64 => UInt64);
-cell_encoding_of!(i8 => Int8);
-cell_encoding_of!(i16 => Int16);
-cell_encoding_of!(i32 => Int32);
-cell_encoding_of!(i64 => Int64);
-cell_encoding_of!(f32 => Float32);
-cell_encoding_of!(f64 => Float64);

@@ -1,184 +1,176 @@
-//! `CellValue` (src/value.rs:12-271 of the reference): a scalar with a run-time cell type.  Scalar arithmetic
-//! stays on the host, as in the reference — one `f64` operation per call; the per-cell form over whole buffers
-//! is what runs on the GPU.  This file also holds the 16-byte `ec_value` image used across the ABI.
+//! [`CellValue`]: one scalar with a run-time cell type.
+//!
+//! PROVENANCE.  The enum shape (`with_ct!(cv_enum)`), the public method signatures and the operator / trait impl
+//! headers are the reference's public surface (erased-cells 0.1.1, src/value.rs:12-271, MIT License, Copyright (c) 2023
+//! Astraea, Inc.); the bodies are this crate's.  See INTEGRATION.md §2 for the line ranges.
+//!
+//! Scalar arithmetic stays on the host, as in the reference — one `f64` operation per call; the per-cell form over whole
+//! buffers is what runs on the GPU.  A `CellValue` crosses the ABI as the 16-byte `ec_value` (tag + 8 payload bytes),
+//! so most of this file works on that image: the payload as a `u64` (`bits`), and the type lattice asked of the library
+//! (`ec_value_convert`) rather than restated here.
 use crate::error::{check, Error, Result};
 use crate::ffi::{ec_value, ec_value_convert};
 use crate::{with_ct, CellEncoding, CellType};
 use num_traits::{One, ToPrimitive, Zero};
+use std::cmp::Ordering;
+use std::ops::{Add, Div, Mul, Neg, Sub};
 
+// api-surface(src/value.rs:11-20): the enum, one variant per cell type in `with_ct!` order
 macro_rules! cv_enum {
     ( $(($id:ident, $p:ident)),*) => {
-        /// Value variants for each [`CellType`]
+        /// A cell outside any buffer: the primitive together with its [`CellType`].
         #[derive(Debug, Copy, Clone)]
         pub enum CellValue { $($id($p)),* }
     }
 }
 with_ct!(cv_enum);
+// end api-surface
+
+/// `on_payload!(value, v => expr)`: `expr` with `v` bound to the primitive inside `value`, whichever variant it is
+/// (the ten arms written out once, here, instead of one `with_ct!` callback per method).
+macro_rules! on_payload {
+    ($value:expr, $v:ident => $body:expr) => {
+        match $value {
+            CellValue::UInt8($v) => $body,
+            CellValue::UInt16($v) => $body,
+            CellValue::UInt32($v) => $body,
+            CellValue::UInt64($v) => $body,
+            CellValue::Int8($v) => $body,
+            CellValue::Int16($v) => $body,
+            CellValue::Int32($v) => $body,
+            CellValue::Int64($v) => $body,
+            CellValue::Float32($v) => $body,
+            CellValue::Float64($v) => $body,
+        }
+    };
+}
 
 impl CellValue {
-    /// Construct new [`CellValue`] from a statically known [`CellEncoding`].
+    /// Wrap a primitive.  (The cell type is `T`'s own: this is `T::into_cell_value`.)
     pub fn new<T: CellEncoding + Sized>(value: T) -> Self {
         value.into_cell_value()
     }
 
-    /// Get the [`CellType`] encoding `self`.
+    /// The tag.
     pub fn cell_type(&self) -> CellType {
-        macro_rules! cv_ct {
-            ($( ($id:ident, $_p:ident) ),*) => {
-                match self {
-                    $(CellValue::$id(_) => CellType::$id),*
-                }
-            };
-        }
-        with_ct!(cv_ct)
+        CellType::from_code(self.to_ffi().dtype)
     }
 
-    /// Get the [`CellValue`] contents as a `T`: `Ok(T)` if `T`'s cell type is the same or wider than the
-    /// encoded value's, `Err(NarrowingError)` if it is narrower.
+    /// The payload as a `T`: widened if `T`'s cell type is wider, `Err(NarrowingError)` if it is narrower.
     pub fn get<T: CellEncoding>(&self) -> Result<T> {
-        let err = || Error::NarrowingError { src: self.cell_type(), dst: T::cell_type() };
-        let cv = self.convert(T::cell_type())?;
-        macro_rules! conv {
-             ($( ($id:ident, $_p:ident) ),*) => {
-                 match cv {
-                     $(CellValue::$id(v) => T::static_cast(v).ok_or_else(err),)*
-                 }
-            };
-        }
-        with_ct!(conv)
+        let widened = self.convert(T::cell_type())?;
+        // after `convert` the payload IS a `T`; `static_cast` only succeeds for the variant that holds one
+        on_payload!(widened, v => T::static_cast(v)).ok_or(Error::NarrowingError { src: self.cell_type(), dst: T::cell_type() })
     }
 
-    /// Convert `self` into a variant with [`CellType`] `cell_type` equal to or wider than its current one
-    /// (the library's host-side `ec_value_convert`: lattice check first, then the `as` cast).
+    /// The same number as a value of `cell_type`.  Legal exactly when `self.cell_type().can_fit_into(cell_type)`; the
+    /// library's host-side `ec_value_convert` checks the lattice and performs the cast (Rust's `as` for every legal
+    /// pair: exact except `u64`/`i64` to `f64`, which round to nearest even).
     pub fn convert(&self, cell_type: CellType) -> Result<Self> {
-        let (src, mut dst) = (self.to_ffi(), CellValue::UInt8(0).to_ffi());
-        check(unsafe { ec_value_convert(&src, cell_type as u8, &mut dst) })?;
-        Ok(CellValue::from_ffi(&dst))
+        let from = self.to_ffi();
+        let mut to = from;
+        check(unsafe { ec_value_convert(&from, cell_type as u8, &mut to) }).map(|()| CellValue::from_ffi(&to))
     }
 
-    /// Converts both values to the smallest cell-type that can contain `self` and `other`.
+    /// Both values in the narrowest cell type that holds both.
     pub fn unify(&self, other: &Self) -> (Self, Self) {
-        let dest = self.cell_type().union(other.cell_type());
-        // `unwrap` is fine: `a.union(b)` holds both `a` and `b` for every pair of the lattice
-        (self.convert(dest).unwrap(), other.convert(dest).unwrap())
+        let common = CellType::union(self.cell_type(), other.cell_type());
+        let lift = |v: &Self| v.convert(common).expect("a union holds both of its operands");
+        (lift(self), lift(other))
     }
 
-    /// The value 0 or 1 (`k`) of cell type `ct` (`CellType::zero` / `CellType::one`).
+    /// 0 or 1 as a value of cell type `ct` (behind `CellType::zero` / `CellType::one`).
     pub(crate) fn small(ct: CellType, k: u8) -> Self {
-        macro_rules! small {
-            ($( ($id:ident, $p:ident) ),*) => {
-                match ct {
-                    $(CellType::$id => CellValue::$id(k as $p),)*
-                }
-            };
-        }
-        with_ct!(small)
+        // u8 widens into every unsigned and float type, i8 into every signed integer type
+        let seed = if ct.is_integral() && ct.is_signed() { CellValue::Int8(k as i8) } else { CellValue::UInt8(k) };
+        seed.convert(ct).expect("0 and 1 exist in every cell type")
     }
 
-    /// `self as f64` (what `to_f64().unwrap()` of src/value.rs:207 yields): exact up to 2^53, round-to-nearest-even above.
+    /// The number as an `f64`: exact up to 2^53, round-to-nearest-even above (`as`).
     pub(crate) fn as_f64(&self) -> f64 {
-        macro_rules! as_f64 {
-            ($( ($id:ident, $_p:ident) ),*) => {
-                match *self {
-                    $(CellValue::$id(v) => v as f64,)*
+        on_payload!(*self, v => v as f64)
+    }
+
+    /// The payload bytes, little-endian, in the low end of a `u64` (the C union of `ec_value`).
+    pub(crate) fn bits(&self) -> u64 {
+        let mut raw = [0u8; 8];
+        on_payload!(*self, v => {
+            let bytes = v.to_le_bytes();
+            raw[..bytes.len()].copy_from_slice(&bytes);
+        });
+        u64::from_le_bytes(raw)
+    }
+
+    /// Inverse of [`CellValue::bits`] for a known cell type.
+    pub(crate) fn from_bits(ct: CellType, b: u64) -> Self {
+        let raw = b.to_le_bytes();
+        macro_rules! rebuild {
+            ( $( ($id:ident, $p:ident) ),* ) => {
+                match ct {
+                    $( CellType::$id => {
+                        let mut own = [0u8; std::mem::size_of::<$p>()];
+                        own.copy_from_slice(&raw[..std::mem::size_of::<$p>()]);
+                        CellValue::$id(<$p>::from_le_bytes(own))
+                    } )*
                 }
             };
         }
-        with_ct!(as_f64)
-    }
-
-    /// The payload as the low bytes of a `u64` (the C union of `ec_value` is 8 little-endian bytes).
-    pub(crate) fn bits(&self) -> u64 {
-        match *self {
-            CellValue::UInt8(v) => v as u64,
-            CellValue::UInt16(v) => v as u64,
-            CellValue::UInt32(v) => v as u64,
-            CellValue::UInt64(v) => v,
-            CellValue::Int8(v) => v as u8 as u64,
-            CellValue::Int16(v) => v as u16 as u64,
-            CellValue::Int32(v) => v as u32 as u64,
-            CellValue::Int64(v) => v as u64,
-            CellValue::Float32(v) => v.to_bits() as u64,
-            CellValue::Float64(v) => v.to_bits(),
-        }
-    }
-
-    pub(crate) fn from_bits(ct: CellType, b: u64) -> Self {
-        match ct {
-            CellType::UInt8 => CellValue::UInt8(b as u8),
-            CellType::UInt16 => CellValue::UInt16(b as u16),
-            CellType::UInt32 => CellValue::UInt32(b as u32),
-            CellType::UInt64 => CellValue::UInt64(b),
-            CellType::Int8 => CellValue::Int8(b as u8 as i8),
-            CellType::Int16 => CellValue::Int16(b as u16 as i16),
-            CellType::Int32 => CellValue::Int32(b as u32 as i32),
-            CellType::Int64 => CellValue::Int64(b as i64),
-            CellType::Float32 => CellValue::Float32(f32::from_bits(b as u32)),
-            CellType::Float64 => CellValue::Float64(f64::from_bits(b)),
-        }
+        with_ct!(rebuild)
     }
 
     pub(crate) fn to_ffi(&self) -> ec_value {
-        ec_value { dtype: self.cell_type() as u8, pad_: [0; 7], bits: self.bits() }
+        let tag = on_payload!(*self, v => cell_type_of(&v)) as u8;
+        ec_value { dtype: tag, pad_: [0; 7], bits: self.bits() }
     }
 
     pub(crate) fn from_ffi(v: &ec_value) -> Self {
         Self::from_bits(CellType::from_code(v.dtype), v.bits)
     }
 
-    /// Order-preserving key of a value among values of ITS cell type: integers as themselves, floats by
-    /// `total_cmp` (−NaN < −inf < … < −0 < +0 < … < +inf < +NaN).
-    fn order_key(&self) -> i128 {
+    /// A key whose integer order is the reference's total order among values of ONE cell type: integers as they are,
+    /// floats as `total_cmp` orders them (sign-magnitude bits folded into two's complement: -NaN < -inf < ... < -0 < +0
+    /// < ... < +inf < +NaN).
+    fn rank(&self) -> i128 {
         match *self {
-            CellValue::UInt8(v) => v as i128,
-            CellValue::UInt16(v) => v as i128,
-            CellValue::UInt32(v) => v as i128,
-            CellValue::UInt64(v) => v as i128,
-            CellValue::Int8(v) => v as i128,
-            CellValue::Int16(v) => v as i128,
-            CellValue::Int32(v) => v as i128,
-            CellValue::Int64(v) => v as i128,
             CellValue::Float32(v) => {
                 let b = v.to_bits() as i32;
-                (b ^ ((((b >> 31) as u32) >> 1) as i32)) as i128
+                i128::from(b ^ (((b >> 31) as u32 >> 1) as i32))
             }
             CellValue::Float64(v) => {
                 let b = v.to_bits() as i64;
-                (b ^ ((((b >> 63) as u64) >> 1) as i64)) as i128
+                i128::from(b ^ (((b >> 63) as u64 >> 1) as i64))
             }
+            CellValue::UInt8(v) => i128::from(v),
+            CellValue::UInt16(v) => i128::from(v),
+            CellValue::UInt32(v) => i128::from(v),
+            CellValue::UInt64(v) => i128::from(v),
+            CellValue::Int8(v) => i128::from(v),
+            CellValue::Int16(v) => i128::from(v),
+            CellValue::Int32(v) => i128::from(v),
+            CellValue::Int64(v) => i128::from(v),
         }
     }
 }
 
-/// Convert from primitive to [`CellValue`].
+fn cell_type_of<T: CellEncoding>(_: &T) -> CellType {
+    T::cell_type()
+}
+
 impl<T: CellEncoding> From<T> for CellValue {
     fn from(value: T) -> Self {
-        value.into_cell_value()
+        CellValue::new(value)
     }
 }
 
-/// Provide `num_traits` interop.
+/// `num_traits` interop: the three required methods delegate to the primitive's own range-checked conversions (the
+/// narrower `to_<p>` of the trait derive from these), except that `to_f64` cannot fail for any cell.
 impl ToPrimitive for CellValue {
     fn to_i64(&self) -> Option<i64> {
-        macro_rules! conv {
-            ($( ($id:ident, $_p:ident) ),*) => {
-                match self {
-                    $(CellValue::$id(v) => v.to_i64(),)*
-                }
-            }
-        }
-        with_ct!(conv)
+        on_payload!(*self, v => ToPrimitive::to_i64(&v))
     }
 
     fn to_u64(&self) -> Option<u64> {
-        macro_rules! conv {
-            ($( ($id:ident, $_p:ident) ),*) => {
-                match self {
-                    $(CellValue::$id(v) => v.to_u64(),)*
-                }
-            }
-        }
-        with_ct!(conv)
+        on_payload!(*self, v => ToPrimitive::to_u64(&v))
     }
 
     fn to_f64(&self) -> Option<f64> {
@@ -189,96 +181,92 @@ impl ToPrimitive for CellValue {
 impl One for CellValue {
     #[inline]
     fn one() -> Self {
-        CellValue::UInt8(1)
+        CellType::UInt8.one()
     }
 }
 
 impl Zero for CellValue {
     #[inline]
     fn zero() -> Self {
-        CellValue::UInt8(0)
+        CellType::UInt8.zero()
     }
 
+    /// Zero of any cell type, `-0.0` included (all payload bits clear once the sign of a float is set aside).
     fn is_zero(&self) -> bool {
-        macro_rules! zero {
-             ($( ($id:ident, $_p:ident) ),*) => {
-                match self {
-                    $(CellValue::$id(v) => v.is_zero(),)*
-                }
-            }
-        }
-        with_ct!(zero)
+        self.as_f64() == 0.0
     }
 }
 
-pub(crate) mod ops {
-    use crate::CellValue;
-    use std::cmp::Ordering;
-    use std::ops::{Add, Div, Mul, Neg, Sub};
-
-    // Every binary op computes `(l as f64) op (r as f64)` and yields `Float64`, for all 100 operand-type pairs
-    // (src/value.rs:199-217): the `unify` in front of the casts is value-preserving, so it is skipped here.
-    macro_rules! cv_bin_op {
-        ($trt:ident, $mth:ident, $op:tt) => {
-            impl <R> $trt<R> for &CellValue where R: Into<CellValue> {
-                type Output = CellValue;
-                fn $mth(self, rhs: R) -> Self::Output {
-                    let rhs: CellValue = rhs.into();
-                    CellValue::Float64(self.as_f64() $op rhs.as_f64())
-                }
-            }
-            impl <R> $trt<R> for CellValue where R: Into<CellValue> {
-                type Output = CellValue;
-                fn $mth(self, rhs: R) -> Self::Output {
-                    $trt::$mth(&self, rhs)
-                }
+// api-surface(src/value.rs:196-271): operator and ordering impl headers of CellValue
+// Arithmetic: for all 100 pairs of operand cell types the reference computes `(l as f64) op (r as f64)` and returns a
+// Float64 (its `unify` in front of the casts changes no value: SURVEY App. A.1), so the operands go to f64 directly.
+macro_rules! value_operator {
+    ($trt:ident, $mth:ident, $f:expr) => {
+        impl<R> $trt<R> for &CellValue
+        where
+            R: Into<CellValue>,
+        {
+            type Output = CellValue;
+            fn $mth(self, rhs: R) -> Self::Output {
+                let f: fn(f64, f64) -> f64 = $f;
+                CellValue::Float64(f(self.as_f64(), rhs.into().as_f64()))
             }
         }
-    }
-    cv_bin_op!(Add, add, +);
-    cv_bin_op!(Sub, sub, -);
-    cv_bin_op!(Mul, mul, *);
-    cv_bin_op!(Div, div, /);
-
-    impl Neg for CellValue {
-        type Output = CellValue;
-        /// src/value.rs:224-240: u8 -> i16, u16 -> i32, u32/u64 -> f64, signed and float types keep theirs.
-        /// A signed MIN wraps, as the reference does in release builds (and as the device kernel does).
-        fn neg(self) -> Self::Output {
-            match self {
-                CellValue::UInt8(v) => CellValue::Int16(-(v as i16)),
-                CellValue::UInt16(v) => CellValue::Int32(-(v as i32)),
-                CellValue::UInt32(v) => CellValue::Float64(-(v as f64)),
-                CellValue::UInt64(v) => CellValue::Float64(-(v as f64)),
-                CellValue::Int8(v) => CellValue::Int8(v.wrapping_neg()),
-                CellValue::Int16(v) => CellValue::Int16(v.wrapping_neg()),
-                CellValue::Int32(v) => CellValue::Int32(v.wrapping_neg()),
-                CellValue::Int64(v) => CellValue::Int64(v.wrapping_neg()),
-                CellValue::Float32(v) => CellValue::Float32(-v),
-                CellValue::Float64(v) => CellValue::Float64(-v),
+        impl<R> $trt<R> for CellValue
+        where
+            R: Into<CellValue>,
+        {
+            type Output = CellValue;
+            fn $mth(self, rhs: R) -> Self::Output {
+                <&CellValue as $trt<R>>::$mth(&self, rhs)
             }
         }
-    }
-
-    impl PartialOrd for CellValue {
-        fn partial_cmp(&self, other: &Self) -> Option<Ordering> {
-            Some(self.cmp(other))
-        }
-    }
-
-    impl Ord for CellValue {
-        /// Unify, then integers by value and floats by `total_cmp` (src/value.rs:248-265).
-        fn cmp(&self, other: &Self) -> Ordering {
-            let (lhs, rhs) = self.unify(other);
-            lhs.order_key().cmp(&rhs.order_key())
-        }
-    }
-
-    impl PartialEq<Self> for CellValue {
-        fn eq(&self, other: &Self) -> bool {
-            Ord::cmp(self, other) == Ordering::Equal
-        }
-    }
-
-    impl Eq for CellValue {}
+    };
 }
+value_operator!(Add, add, |a, b| a + b);
+value_operator!(Sub, sub, |a, b| a - b);
+value_operator!(Mul, mul, |a, b| a * b);
+value_operator!(Div, div, |a, b| a / b);
+
+impl Neg for CellValue {
+    type Output = CellValue;
+    /// Unsigned cells need room for the sign: u8 -> i16, u16 -> i32, u32 and u64 -> f64.  Signed and float cells keep
+    /// their type; a signed MIN wraps, as the reference does in release builds and as the device kernel does.
+    fn neg(self) -> Self::Output {
+        match self {
+            CellValue::UInt8(v) => CellValue::Int16(-i16::from(v)),
+            CellValue::UInt16(v) => CellValue::Int32(-i32::from(v)),
+            CellValue::UInt32(v) => CellValue::Float64(-f64::from(v)),
+            CellValue::UInt64(v) => CellValue::Float64(-(v as f64)),
+            CellValue::Int8(v) => CellValue::Int8(v.wrapping_neg()),
+            CellValue::Int16(v) => CellValue::Int16(v.wrapping_neg()),
+            CellValue::Int32(v) => CellValue::Int32(v.wrapping_neg()),
+            CellValue::Int64(v) => CellValue::Int64(v.wrapping_neg()),
+            CellValue::Float32(v) => CellValue::Float32(-v),
+            CellValue::Float64(v) => CellValue::Float64(-v),
+        }
+    }
+}
+
+impl PartialOrd for CellValue {
+    fn partial_cmp(&self, other: &Self) -> Option<Ordering> {
+        Some(Ord::cmp(self, other))
+    }
+}
+
+impl Ord for CellValue {
+    /// Values of different cell types are unified first; then integers compare by value and floats by `total_cmp`.
+    fn cmp(&self, other: &Self) -> Ordering {
+        let (a, b) = self.unify(other);
+        a.rank().cmp(&b.rank())
+    }
+}
+
+impl PartialEq<Self> for CellValue {
+    fn eq(&self, other: &Self) -> bool {
+        self.cmp(other).is_eq()
+    }
+}
+
+impl Eq for CellValue {}
+// end api-surface

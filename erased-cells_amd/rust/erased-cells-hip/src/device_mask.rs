@@ -1,4 +1,8 @@
-//! `Mask` (src/masked/mask.rs of the reference): the image of `Vec<bool>` in HBM, one byte per cell, 0 or 1.
+//! [`Mask`]: the image of a `Vec<bool>` in HBM, one byte per cell, 0 or 1.
+//!
+//! PROVENANCE.  The type's name, its method signatures and its trait / operator impl headers are the reference's public
+//! surface (erased-cells 0.1.1, src/masked/mask.rs:10-178, MIT License, Copyright (c) 2023 Astraea, Inc.); the bodies
+//! and the host-shadow mechanism are this crate's.  See INTEGRATION.md §2.
 //!
 //! The reference hands out `&mut bool` (`iter_mut`, `IndexMut`): those need host memory.  A `Mask` therefore keeps
 //! an optional host shadow: `iter_mut` / `index_mut` fill it from the device, mark it dirty and lend references
@@ -15,7 +19,7 @@ use std::ops::{BitAnd, BitOr, Index, IndexMut, Not};
 use std::os::raw::c_void;
 use std::vec::IntoIter;
 
-/// Encodes the bit-mask for [`MaskedCellBuffer`][super::MaskedCellBuffer]
+/// Which cells of a [`MaskedCellBuffer`][super::MaskedCellBuffer] are data (`true`) and which are no-data (`false`).
 pub struct Mask {
     pub(crate) len: usize,
     pub(crate) mem: DeviceMem,
@@ -54,14 +58,14 @@ impl Mask {
         download::<u8>(self.dev_ptr() as *const c_void, self.len).into_iter().map(|b| b != 0).collect()
     }
 
-    /// Create a new mask containing `values`.
+    /// Upload `values` as they are.
     pub fn new(values: Vec<bool>) -> Self {
         let out = Self::uninit(values.len());
         upload(out.mem.ptr(), &values); // `bool` is one byte holding 0 or 1: the Vec is already the device image
         out
     }
 
-    /// Create a mask of size `len` with all values set to `value`.
+    /// `len` flags, all `value` (a fill kernel; nothing is uploaded).
     pub fn fill(len: usize, value: bool) -> Self {
         let out = Self::uninit(len);
         let v = crate::CellValue::UInt8(value as u8).to_ffi();
@@ -69,8 +73,7 @@ impl Mask {
         out
     }
 
-    /// Create a mask of size `len` were each value is determined by the value returned by `f`, which is called
-    /// with the index position as an argument.
+    /// Flag `i` is `f(i)`: evaluated on the host, uploaded once.
     pub fn fill_via<F>(len: usize, f: F) -> Self
     where
         F: Fn(usize) -> bool,
@@ -78,20 +81,20 @@ impl Mask {
         Self::new((0..len).map(f).collect())
     }
 
-    /// Get the number of mask elements.
+    /// Number of flags.
     pub fn len(&self) -> usize {
         self.len
     }
 
-    /// Returns `true` if `self.len() == 0`.
+    /// `len() == 0`.
     pub fn is_empty(&self) -> bool {
         self.len() == 0
     }
 
-    /// Set the mask value at position `index` to `value`.
+    /// Overwrite one flag (a one-byte upload; the host shadow, if there is one, follows).
     ///
     /// # Panics
-    /// Will panic if `index` >= `self.len()`.
+    /// If `index >= self.len()`.
     pub fn put(&mut self, index: usize, value: bool) {
         assert!(index < self.len, "index out of bounds: the len is {} but the index is {}", self.len, index);
         let p = unsafe { (self.dev_ptr() as *mut u8).add(index) } as *mut c_void;
@@ -101,10 +104,10 @@ impl Mask {
         }
     }
 
-    /// Get the mask value at position `index`.
+    /// One flag: from the host shadow when it is current, else a one-byte download.
     ///
     /// # Panics
-    /// Will panic if `index` >= `self.len()`.
+    /// If `index >= self.len()`.
     pub fn get(&self, index: usize) -> bool {
         assert!(index < self.len, "index out of bounds: the len is {} but the index is {}", self.len, index);
         if self.shadow.len() == self.len {
@@ -113,21 +116,21 @@ impl Mask {
         download::<u8>(unsafe { self.dev_ptr().add(index) } as *const c_void, 1)[0] != 0
     }
 
-    /// Gets an mutable iterator over values in mask, in sequence (over the host shadow; written back before the
-    /// next device-side use).
+    /// `&mut bool` access needs host memory: the flags are brought into the host shadow, lent out from there, and
+    /// written back before the device next reads the mask.
     pub fn iter_mut(&mut self) -> impl Iterator<Item = &'_ mut bool> {
         self.load_shadow();
         self.dirty.set(true);
         self.shadow.iter_mut()
     }
 
-    /// Determine if all mask values equal `value`.
+    /// Are all flags `value`?  (Answered from `counts`: one device reduction.)
     pub fn all(&self, value: bool) -> bool {
         let (data, nodata) = self.counts();
         if value { nodata == 0 } else { data == 0 }
     }
 
-    /// Returns a tuple of representing counts of `(data, nodata)`.
+    /// `(data, nodata)` = (number of `true`, number of `false`) flags — a device reduction over the bytes.
     pub fn counts(&self) -> (usize, usize) {
         let (mut t, mut f) = (0u64, 0u64);
         must(unsafe { ec_mask_counts(self.dev_ptr(), self.len, &mut t, &mut f, stream()) }, "ec_mask_counts");

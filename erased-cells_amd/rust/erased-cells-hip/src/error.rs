@@ -1,9 +1,13 @@
-//! Crate-wide `Result` / `Error` (the reference's `error` module, src/error.rs:9-27, plus one variant for
-//! failures of the HIP backend, which the CPU crate cannot have).
+//! `Result` / `Error` of the crate.
+//!
+//! PROVENANCE.  The `Error` enum — its variants and their messages, which callers may match on or print — is the
+//! reference's (erased-cells 0.1.1, src/error.rs:9-27, MIT License, Copyright (c) 2023 Astraea, Inc.) plus one variant
+//! of this crate's for failures of the HIP backend, which a CPU crate cannot have.  See INTEGRATION.md §2.
 use crate::ffi::*;
 use crate::CellType;
 use std::ffi::CStr;
 
+// api-surface(src/error.rs:9-27): the Result alias and the Error enum with the reference's five variants and messages
 pub type Result<T, E = Error> = std::result::Result<T, E>;
 
 #[derive(thiserror::Error, Debug)]
@@ -23,6 +27,7 @@ pub enum Error {
     #[error("HIP backend: {0}")]
     Backend(String),
 }
+// end api-surface
 
 /// `ec_status` -> `Result`: `EC_ERR_NARROWING` becomes `Error::NarrowingError { src, dst }` again.
 pub(crate) fn check(st: ec_status) -> Result<()> {

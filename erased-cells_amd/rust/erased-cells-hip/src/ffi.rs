@@ -23,6 +23,8 @@ pub struct ec_shard_group {
 }
 pub const EC_GROUP_RCCL: u32 = 0;
 pub const EC_GROUP_HOST_COMBINE: u32 = 1;
+/// Every sharded call waits until all launch threads have issued (the form of rounds 1-2; default: fire-and-forget).
+pub const EC_GROUP_BLOCKING_ISSUE: u32 = 2;
 /// `ec_shard_fn`: called once per shard on that shard's launch thread.
 pub type ec_shard_fn = extern "C" fn(shard: i32, device: i32, stream: ec_stream, user: *mut c_void) -> ec_status;
 

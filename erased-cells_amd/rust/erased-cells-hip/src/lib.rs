@@ -12,41 +12,48 @@
 //! (row-block shards over the GPUs of a node), [`init`] / [`set_stream`].
 //!
 //! NOT COMPILED in the build image (no rustc there); `tests/test_rust_surface.py` keeps the public items in
-//! lockstep with the reference's and `ffi.rs` in lockstep with the header.  The same mapping, compiled and
-//! tested, exists in C++ (`host/erased_cells.hpp`) and Python (`python/erased_cells_hip`); see INTEGRATION.md.
+//! lockstep with the reference's and `ffi.rs` in lockstep with the header, parameter types included.  The same
+//! mapping, compiled and tested, exists in C++ (`host/erased_cells.hpp`) and Python (`python/erased_cells_hip`).
+//!
+//! PROVENANCE.  This crate is a derived work of erased-cells 0.1.1 (MIT License, Copyright (c) 2023 Astraea, Inc.):
+//! its public item declarations — names, signatures, trait and operator impl headers, the `with_ct!` table — are the
+//! reference's, kept verbatim where a drop-in needs them and marked `api-surface(<reference file>:<lines>)` in the
+//! source; everything between and inside them is this crate's own.  INTEGRATION.md §2 lists every marked range;
+//! `tests/test_rust_provenance.py` holds the list and the sources together.
 pub mod ffi;
 
 mod cell_type;
 mod cell_value;
+mod encoding;
 mod device;
 mod device_buffer;
 #[cfg(feature = "masked")]
 mod device_mask;
-#[path = "errors.rs"]
 pub mod error;
 pub mod fused;
 #[cfg(feature = "masked")]
-mod masked;
+mod masked_buffer;
 #[cfg(feature = "masked")]
-mod sentinel;
+mod nodata;
 pub mod sharded;
 
 pub use cell_type::*;
 pub use cell_value::*;
+pub use encoding::*;
 pub use device::{init, set_stream, stream};
 pub use device_buffer::*;
 #[cfg(feature = "masked")]
 pub use device_mask::*;
 #[cfg(feature = "masked")]
-pub use masked::*;
+pub use masked_buffer::*;
 #[cfg(feature = "masked")]
-pub use sentinel::*;
+pub use nodata::*;
 use std::fmt::{Debug, Formatter};
 
-/// `with_ct` is a callback style macro used to construct various implementations covering all [`CellType`]s.
-///
-/// It calls the passed identifier as a macro with two parameters: the cell type id (e.g. `UInt8`) and the cell
-/// type primitive (e.g. `u8`), for each of the ten encodings, in discriminant order.
+// api-surface(src/lib.rs:60-101): the `with_ct!` table
+/// Callback macro over the ten cell encodings: `with_ct!(m)` expands to `m! { (UInt8, u8), (UInt16, u16), ... (Float64, f64) }`
+/// — the pairs of `CellType` variant and Rust primitive in discriminant order (which is also the ABI's dtype code order).
+/// This is how the crate, like the reference, stamps out anything that must exist once per cell type.
 #[macro_export]
 macro_rules! with_ct {
     ($callback:ident) => {
@@ -64,62 +71,65 @@ macro_rules! with_ct {
         }
     };
 }
+// end api-surface
 
-/// Operations common to buffers of [`CellValue`]s.
+// api-surface(src/lib.rs:103-163): trait BufferOps (the method set and signatures; the doc comments are this crate's)
+/// What [`CellBuffer`] and [`MaskedCellBuffer`] have in common.  Every method that touches cells is a call into the
+/// library on HBM-resident data; what each costs is noted where it differs from a host `Vec`.
 pub trait BufferOps {
-    /// Construct a [`CellBuffer`] from a `Vec<T>`.
+    /// Upload `data` (one host-to-HBM copy); the cell type is `T`'s.
     fn from_vec<T: CellEncoding>(data: Vec<T>) -> Self;
 
-    /// Construct a [`CellBuffer`] of given `len` length and `ct` `CellType`, filled with the type's default value.
+    /// `len` cells of type `ct`, all zero (a fill kernel; nothing is uploaded).
     fn with_defaults(len: usize, ct: CellType) -> Self;
 
-    /// Create a buffer of size `len` with all values `value`.
+    /// `len` copies of `value`; the buffer takes `value`'s cell type.
     fn fill(len: usize, value: CellValue) -> Self;
 
-    /// Fill a buffer of size `len` with values from a closure called with the current index.
+    /// Cell `i` is `f(i)`: evaluated on the host, uploaded once.
     fn fill_via<T, F>(len: usize, f: F) -> Self
     where
         T: CellEncoding,
         F: Fn(usize) -> T;
 
-    /// Get the length of the buffer.
+    /// Number of cells.
     fn len(&self) -> usize;
 
-    /// Determine if the buffer has zero values in it.
+    /// `len() == 0`.
     fn is_empty(&self) -> bool {
         self.len() == 0
     }
 
-    /// Get the cell-type of the encoded value.
+    /// The cell type every cell of the buffer has.
     fn cell_type(&self) -> CellType;
 
-    /// Get the [`CellValue`] at index `idx`.
+    /// One cell, downloaded (a device round trip: iterate or `to_vec` to read many).
     ///
     /// # Panics
-    /// Will panic if `index` >= `self.len()`.
+    /// If `index >= self.len()`.
     fn get(&self, index: usize) -> CellValue;
 
-    /// Store `value` at position `idx`.
-    ///
-    /// Returns `Err(NarrowingError)` if `value.cell_type() != self.cell_type()` and overflow could occur.
+    /// Overwrite one cell.  `value` is widened to the buffer's cell type first; `Err(NarrowingError)` (and nothing
+    /// written) if its own cell type does not fit.
     ///
     /// # Panics
-    /// Will panic if `index` >= `self.len()`.
+    /// If `index >= self.len()`.
     fn put(&mut self, index: usize, value: CellValue) -> error::Result<()>;
 
-    /// Create a new buffer whereby all [`CellValue`]s are converted to `cell_type`.
-    ///
-    /// Returns `Err(NarrowingError)` if `cell_type` is narrower than the buffer's cell type.
+    /// A new buffer with every cell widened to `cell_type` (one kernel); the same type gives a device-to-device copy.
+    /// `Err(NarrowingError)` before any device work when `cell_type` cannot hold the buffer's type.
     fn convert(&self, cell_type: CellType) -> error::Result<Self>
     where
         Self: Sized;
 
-    /// Compute the minimum and maximum values the buffer.
+    /// `(min, max)` under the total order (integers by value, floats by `total_cmp`), typed as the buffer: a device
+    /// reduction.  Folded from `(T::MAX, T::MIN)`, so an empty buffer returns that inverted pair.
     fn min_max(&self) -> (CellValue, CellValue);
 
-    /// Convert `self` into a `Vec<T>`.
+    /// Widen to `T` on the device if needed, then download (`Err(NarrowingError)` if `T` is narrower).
     fn to_vec<T: CellEncoding>(self) -> error::Result<Vec<T>>;
 }
+// end api-surface
 
 /// Newtype wrapper for debug rendering: more than ten items show as the first five, `, ... `, the last five.
 pub(crate) struct Elided<'a, T>(&'a [T]);

@@ -146,7 +146,8 @@ impl ShardGroup {
         Ok(ShardedCellBuffer { group: self, ct: T::cell_type(), ptrs, lens })
     }
 
-    /// Wait for every shard's stream.
+    /// Wait until everything queued so far has been issued and every shard's stream has drained.  The element-wise
+    /// sharded calls are fire-and-forget: a failure inside one of them (a launch error) is reported here, once.
     pub fn sync(&self) -> Result<()> {
         check(unsafe { ec_shard_group_sync(self.g) })
     }

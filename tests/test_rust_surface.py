@@ -3,7 +3,8 @@ public surface is held in lockstep with the reference's by text: every `pub fn`,
 trait/enum/struct/type` and `impl ... for ...` header of the reference files on the path (src/lib.rs, buffer.rs,
 value.rs, ctype.rs, encoding.rs, error.rs, masked/*.rs — unit-test modules excluded) must appear, same name and
 same signature, in the crate.  Runs only where the reference tree is present (this container); on a box without
-it the test is skipped — nothing of the reference is stored in the repository."""
+it the test is skipped.  (The crate itself does reproduce the reference's declarations — that is the point of a
+drop-in; which lines, under which licence, is recorded in INTEGRATION.md §2 and held by tests/test_rust_provenance.py.)"""
 import os
 import re
 
