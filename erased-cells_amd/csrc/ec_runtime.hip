@@ -67,6 +67,29 @@ struct ScratchEntry {
     uint64_t stamp = 0;  // last use, for eviction
 };
 
+}  // namespace ecd (reopened below: ScratchOwner is named in ec_runtime.hpp)
+
+// Owns one stream's scratch allocations.  Destroyed when the table's entry AND every copy a caller still holds are gone —
+// on whatever thread drops the last one, never while the runtime's table lock is held (hipFree waits for the device).
+struct ecd::ScratchOwner {
+    int device = -1;
+    int64_t* dev = nullptr;
+    int64_t* host = nullptr;
+    std::mutex* mu = nullptr;
+    ~ScratchOwner() {
+        int before = -1;
+        const bool had = hipGetDevice(&before) == hipSuccess;
+        if (device >= 0 && (!had || before != device)) (void)hipSetDevice(device);
+        (void)hipFree(dev);
+        (void)hipHostFree(host);
+        delete mu;
+        if (had && before != device) (void)hipSetDevice(before);
+        (void)hipGetLastError();
+    }
+};
+
+namespace ecd {
+
 struct DeviceState {
     int device = -1;
     int cus = 256;
@@ -96,12 +119,7 @@ Tuning& tuning() { return g_tuning; }
 int device_cus() { return t_cus; }
 int current_device() { return t_active; }
 
-static void free_scratch(Scratch& sc) {
-    (void)hipFree(sc.dev);
-    (void)hipHostFree(sc.host);
-    delete sc.mu;
-    sc = Scratch{};
-}
+// (freeing a stream's scratch = dropping the table's reference: ScratchOwner's destructor does the work once nobody uses it)
 
 ec_status ensure_ready() {
     if (t_generation != g_generation.load(std::memory_order_acquire)) {
@@ -128,6 +146,7 @@ ec_status ensure_ready() {
 }
 
 ec_status get_scratch(hipStream_t s, Scratch* out) {
+    std::shared_ptr<ScratchOwner> evicted;  // destroyed after the lock is released
     std::lock_guard<std::mutex> lk(g_mu);
     auto dit = g_devs.find(t_active);
     if (dit == g_devs.end()) return set_error(EC_ERR_NOT_INITIALIZED, "get_scratch: no device bound");
@@ -135,28 +154,37 @@ ec_status get_scratch(hipStream_t s, Scratch* out) {
     auto it = table.find(s);
     if (it == table.end()) {
         if (table.size() >= kMaxScratchPerDevice) {
-            auto victim = table.begin();
+            // least recently used entry that nobody is inside of (only the table references it)
+            auto victim = table.end();
             for (auto k = table.begin(); k != table.end(); ++k)
-                if (k->second.stamp < victim->second.stamp) victim = k;
-            free_scratch(victim->second.sc);
-            table.erase(victim);
+                if (k->second.sc.owner.use_count() == 1 && (victim == table.end() || k->second.stamp < victim->second.stamp)) victim = k;
+            if (victim != table.end()) {
+                evicted = std::move(victim->second.sc.owner);
+                table.erase(victim);
+            }  // else: every entry is in use right now — the table grows past its bound for the moment
         }
         ScratchEntry e;
-        ec_status st = check_hip(hipMalloc(reinterpret_cast<void**>(&e.sc.dev), (2 * kMaxReduceBlocks + 4) * sizeof(int64_t)),
+        auto own = std::make_shared<ScratchOwner>();
+        own->device = t_active;
+        ec_status st = check_hip(hipMalloc(reinterpret_cast<void**>(&own->dev), (2 * kMaxReduceBlocks + 4) * sizeof(int64_t)),
                                  "hipMalloc(scratch)");
         if (st != EC_OK) return st;
-        st = check_hip(hipHostMalloc(reinterpret_cast<void**>(&e.sc.host), 4 * sizeof(int64_t), hipHostMallocDefault),
+        st = check_hip(hipHostMalloc(reinterpret_cast<void**>(&own->host), 4 * sizeof(int64_t), hipHostMallocDefault),
                        "hipHostMalloc(scratch)");
-        if (st != EC_OK) { (void)hipFree(e.sc.dev); return st; }
+        if (st != EC_OK) return st;  // `own` frees what it has
+        own->mu = new std::mutex;
+        e.sc.dev = own->dev;
+        e.sc.host = own->host;
+        e.sc.mu = own->mu;
         void* as_device = nullptr;
         static const bool no_zero_copy = std::getenv("EC_NO_ZERO_COPY_RESULTS") != nullptr;  // A/B switch
         if (!no_zero_copy && hipHostGetDevicePointer(&as_device, e.sc.host, 0) == hipSuccess && as_device) e.sc.host_dev = static_cast<int64_t*>(as_device);
         else (void)hipGetLastError();  // host_dev stays null: results go through dev_result() and a copy
-        e.sc.mu = new std::mutex;
+        e.sc.owner = std::move(own);
         it = table.emplace(s, e).first;
     }
     it->second.stamp = ++g_stamp;
-    *out = it->second.sc;
+    *out = it->second.sc;  // shares ownership
     return EC_OK;
 }
 
@@ -240,8 +268,7 @@ extern "C" ec_status ec_shutdown(void) {
     for (auto& kv : g_devs) {
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
-        for (auto& se : kv.second.scratch) free_scratch(se.second.sc);
-        kv.second.scratch.clear();
+        kv.second.scratch.clear();  // no call is in flight at shutdown: the owners free their memory here
         if (kv.second.pool) {
             (void)hipMemPoolTrimTo(kv.second.pool, 0);
             (void)hipMemPoolDestroy(kv.second.pool);
@@ -312,19 +339,33 @@ extern "C" ec_status ec_free_async(void* dptr, ec_stream stream) {
 }
 
 // Free of a block whose last use may be on another stream than the one it is returned on: the free is ordered
-// after everything enqueued so far on `last_use_stream` (event + wait), then queued on `alloc_stream`.
+// after everything enqueued so far on `last_use_stream` (event + wait), then queued on `alloc_stream`.  The calling
+// thread may be bound to another device than the block's (a destructor run by a garbage collector, a thread that
+// moved on with ec_set_device): the block's own device is looked up and made current for the duration.  If the
+// event path fails the free still happens, behind a wait for `last_use_stream` — a block is never leaked.
 extern "C" ec_status ec_free_ordered(void* dptr, ec_stream alloc_stream, ec_stream last_use_stream) {
     if (!dptr) return EC_OK;
+    int before = -1, owner = -1;
+    const bool had = hipGetDevice(&before) == hipSuccess;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, dptr) == hipSuccess) owner = attr.device;
+    else (void)hipGetLastError();
+    const bool moved = owner >= 0 && had && owner != before && hipSetDevice(owner) == hipSuccess;
+    ec_status st = EC_OK;
     if (alloc_stream != last_use_stream) {
-        hipEvent_t ev;
-        ec_status st = check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
-        if (st != EC_OK) return st;
-        st = check_hip(hipEventRecord(ev, S(last_use_stream)), "hipEventRecord");
+        hipEvent_t ev = nullptr;
+        st = check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        if (st == EC_OK) st = check_hip(hipEventRecord(ev, S(last_use_stream)), "hipEventRecord");
         if (st == EC_OK) st = check_hip(hipStreamWaitEvent(S(alloc_stream), ev, 0), "hipStreamWaitEvent");
-        (void)hipEventDestroy(ev);  // released once the wait has consumed it
-        if (st != EC_OK) return st;
+        if (ev) (void)hipEventDestroy(ev);  // released once the wait has consumed it
+        if (st != EC_OK) {  // order the hard way instead of leaking the block
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(S(last_use_stream));
+        }
     }
-    return check_hip(hipFreeAsync(dptr, S(alloc_stream)), "hipFreeAsync");
+    const ec_status freed = check_hip(hipFreeAsync(dptr, S(alloc_stream)), "hipFreeAsync");
+    if (moved) (void)hipSetDevice(before);
+    return freed != EC_OK ? freed : EC_OK;
 }
 
 extern "C" ec_status ec_pool_trim(size_t keep_bytes) {
@@ -381,17 +422,22 @@ extern "C" ec_status ec_prepare_stream(ec_stream stream) {
     return get_scratch(S(stream), &sc);  // allocates this stream's reduction scratch now, not at first use
 }
 
-// Releases the reduction scratch the library holds for `stream` (any stream, also one it did not create).
+// Releases the reduction scratch the library holds for `stream` (any stream, also one it did not create).  The memory
+// goes once no call is using it any more.  A stream with reductions captured in a hipGraph must not be released while
+// the graph may still be replayed: the graph's kernels carry the scratch addresses.
 extern "C" ec_status ec_release_stream(ec_stream stream) {
     ec_status st = ensure_ready();
     if (st != EC_OK) return st;
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto dit = g_devs.find(t_active);
-    if (dit == g_devs.end()) return EC_OK;
-    auto it = dit->second.scratch.find(S(stream));
-    if (it != dit->second.scratch.end()) {
-        free_scratch(it->second.sc);
-        dit->second.scratch.erase(it);
+    std::shared_ptr<ScratchOwner> released;  // destroyed after the lock is released
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto dit = g_devs.find(t_active);
+        if (dit == g_devs.end()) return EC_OK;
+        auto it = dit->second.scratch.find(S(stream));
+        if (it != dit->second.scratch.end()) {
+            released = std::move(it->second.sc.owner);
+            dit->second.scratch.erase(it);
+        }
     }
     return EC_OK;
 }

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <string>
 
@@ -133,7 +134,12 @@ inline unsigned grid_capped(size_t blocks, int bpc) {
 // partials are ordered by the stream itself; `mu` serialises the synchronous-result entry points (ec_min_max,
 // ec_mask_counts, ec_first_difference), which read `host` after waiting for the stream — two host threads sharing
 // one stream therefore take turns instead of racing on the four pinned words.
+struct ScratchOwner;  // frees the three allocations when the last Scratch copy that names them is gone (ec_runtime.hip)
 struct Scratch {
+    std::shared_ptr<ScratchOwner> owner;  // every copy handed out by get_scratch() shares ownership: releasing or recycling a
+                                          // stream's entry only drops the TABLE's reference, so a host thread that is
+                                          // inside ec_min_max / ec_mask_counts / ec_first_difference with this scratch
+                                          // (its `mu` locked, its kernels queued) keeps valid memory until it returns
     int64_t* dev = nullptr;    // 2*kMaxReduceBlocks partials + 4 result words
     int64_t* host = nullptr;   // 4 words, pinned (coherent): the synchronous-result entry points let the last kernel write
                                // its result straight into them — no device-to-host copy is queued behind the kernel
