@@ -24,7 +24,7 @@ CELLS = 16384 * 16384
 # workload -> (algorithmic bytes per cell per step, input bytes per cell per step, kernels that make up one step)
 WORKLOADS = {
     "div": (11, 3, ["k_binop_direct"]),
-    "masked_chain": (42, 26, ["k_masked_binop"]),
+    "masked_chain": (42, 24, ["k_masked_binop"]),
     "masked_chain_fused": (24, 15, ["k_fused_any", "k_fused_same"]),
     "minmax": (2, 2, ["k_min_max_partials", "k_min_max_finalize"]),
     "ndvi_fused": (12, 4, ["k_fused_any", "k_fused_same"]),
