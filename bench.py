@@ -539,7 +539,7 @@ def main():
             del r
         if args.e2e and world == 1 and args.workload == "div_u8_u16":
             res["end_to_end_pcie_pipelined"] = e2e_pipelined(torch, ec, L, a, b, out, n)
-        if world == 1 and not args.no_fresh_inputs and args.workload == "div_u8_u16":
+        if not args.no_fresh_inputs and args.workload == "div_u8_u16":  # at N > 1: rank 0's shard (the others wait at the barrier)
             # The K timed steps read the SAME operands, and the u8 operand of a 16384² raster is 256 MiB — the size of the
             # Infinity Cache: the library loads an operand that fits the cache with the default policy (cache_plan,
             # csrc/ec_runtime.hpp), so from the second step on it is served on-die and `roofline.achieved` above counts
@@ -569,7 +569,7 @@ def main():
             fresh = bytes_per_cell * n / (fresh_ms * 1e-3) / 1e9
             res["roofline"]["fresh_inputs"] = {
                 "launch_ms": fresh_ms, "achieved": fresh, "frac": fresh / HBM_PEAK_GBPS, "Gcells_per_s": n / (fresh_ms * 1e-3) / 1e9,
-                "operand_sets": 4, "launches": reps,
+                "operand_sets": 4, "launches": reps, "rank": 0, "cells": n,
                 "what": "the same kernel over 4 operand sets in rotation, so that no operand byte is still in the 256 MiB Infinity "
                         "Cache when it is read again: every algorithmic byte moves from / to HBM.  The timed steps above re-read one "
                         "operand set; its 256 MiB u8 operand is loaded with the default cache policy and stays on-die between steps."}
