@@ -484,7 +484,8 @@ def main():
         dist.all_gather_object(dev_ids, dev_id)
     else:
         dev_ids = [dev_id]
-    if rank == 0 and world > 1 and not args.single_device and len(set(dev_ids)) != world:
+    identifiable = all("uuid=?" not in d or "pci=?" not in d for d in dev_ids)  # a build without uuid / PCI ids cannot tell
+    if rank == 0 and world > 1 and not args.single_device and identifiable and len(set(dev_ids)) != world:
         sys.exit(f"bench.py: the {world} ranks do not sit on {world} distinct GPUs: {dev_ids}")
     elapsed = max(r[0] for r in per_rank)          # MAX over ranks
     slowest = max(range(len(per_rank)), key=lambda i: per_rank[i][1])

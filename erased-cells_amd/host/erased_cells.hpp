@@ -817,8 +817,9 @@ template <typename B> inline B eval(const Tree<B>& t) { return expr(*t.l.l, t.l.
 
 // ---------------------------------------------------------------- one process, all GPUs of the node
 // Row-block shards over an ec_shard_group: shard i on device i, a launch thread + stream + RCCL communicator per
-// device inside the library.  Element-wise ops fan out without communication; min_max / counts all-reduce their
-// 16-byte payloads over xGMI.  (One process per GPU instead: ec_comm_init_rank + ec_allreduce_*.)
+// device inside the library.  Element-wise ops are queued for the launch threads and return at once (fire-and-forget:
+// a failure inside one is reported by the next sync() / reduction); min_max / counts all-reduce their 16-byte payloads
+// over xGMI and wait for the result.  (One process per GPU instead: ec_comm_init_rank + ec_allreduce_*.)
 namespace sharded {
 
 class ShardGroup {
@@ -834,7 +835,14 @@ public:
     ShardGroup& operator=(const ShardGroup&) = delete;
     ec_shard_group* raw() const { return g_; }
     int size() const { return n_; }
+    // waits for everything queued so far; throws the first failure a fire-and-forget call left behind
     void sync() const { check(ec_shard_group_sync(g_)); }
+    // "jobs_posted", "poisoned", "blocking_issue"
+    int64_t stat(const char* key) const {
+        int64_t v = 0;
+        check(ec_shard_group_stat(g_, key, &v));
+        return v;
+    }
 };
 
 class ShardedCellBuffer {

@@ -99,11 +99,15 @@ class ShardGroup:
     of the clique inside the library.  `host_combine=True` folds the 16-byte reduction payloads on the host instead of
     over xGMI (no RCCL; lets one device be listed several times, e.g. to rehearse on a 1-GPU box)."""
 
-    def __init__(self, devices, host_combine: bool = False):
+    def __init__(self, devices, host_combine: bool = False, blocking_issue: bool = False):
+        """`blocking_issue=True`: every element-wise call waits until all launch threads have issued (the form of rounds
+        1-2); default: the calls are queued for the launch threads and return at once, a failure inside one is raised by
+        the next `sync()` / reduction."""
         self.n = len(devices)
         self.handle = C.c_void_p()
         arr = (C.c_int32 * self.n)(*devices)
-        check(lib().ec_shard_group_create(arr, self.n, 1 if host_combine else 0, C.byref(self.handle)))
+        flags = (1 if host_combine else 0) | (2 if blocking_issue else 0)
+        check(lib().ec_shard_group_create(arr, self.n, flags, C.byref(self.handle)))
 
     def close(self) -> None:
         if self.handle:
@@ -122,7 +126,13 @@ class ShardGroup:
         return dev.value, st.value
 
     def sync(self) -> None:
+        """Everything queued so far has been issued and has finished; raises the first failure a queued call left behind."""
         check(lib().ec_shard_group_sync(self.handle))
+
+    def stat(self, key: str) -> int:
+        v = C.c_int64()
+        check(lib().ec_shard_group_stat(self.handle, key.encode(), C.byref(v)))
+        return v.value
 
     def foreach(self, fn) -> None:
         """fn(shard, device, stream) on every shard's own launch thread (its device current); any ABI call may be made
