@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--side", type=int, default=16384, help="raster is side x side cells")
     ap.add_argument("--rows", type=int, default=None,
                     help="raster rows (default: side); e.g. --rows 2048 times on one GPU the row-block one rank owns at N=8")
-    ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax", "ndvi", "binop"])
+    ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax", "ndvi", "binop", "evi"])
     ap.add_argument("--lt", default="u16", help="--workload binop: lhs cell type (u8 u16 u32 u64 i8 i16 i32 i64 f32 f64)")
     ap.add_argument("--rt", default="u16", help="--workload binop: rhs cell type")
     ap.add_argument("--op", default="add", choices=["add", "sub", "mul", "div"], help="--workload binop: operator")
@@ -387,6 +387,44 @@ def main():
                 chk(L.ec_binop(ec.ADD, ec.UInt16, nir.mem.ptr, red_t, red.mem.ptr, n, t2.mem.ptr, stream))
                 chk(L.ec_binop(ec.DIV, ec.Float64, t1.mem.ptr, ec.Float64, t2.mem.ptr, n, out.mem.ptr, stream))
         wl = f"{side}x{side} u16 NDVI (nir-red)/(nir+red) (BASELINE configs[4] arithmetic at raster scale), " + ("fused" if args.fused else "eager")
+    elif args.workload == "evi":  # a tree deeper than two levels: 2.5*(nir-red) / (nir + 6*red - 7.5*blue + 1), 8 operators
+        E = ec._ffi
+        nir, red, blue = (ec.CellBuffer.empty(n, ec.UInt16) for _ in range(3))
+        for i, bf in enumerate((nir, red, blue)):
+            chk(L.ec_synth_fill(ec.UInt16, bf.mem.ptr, n, 0x5EED0031 + i, off, 2000.0 + 3000.0 * (2 - i), 20000.0 + 10000.0 * (2 - i), stream))
+        out = ec.CellBuffer.empty(n, ec.Float64)
+        traffic_key = "evi" + ("_fused" if args.fused else "")
+        sc = (E.EcValue * 4)(*[ec.CellValue.new(x).to_ec() for x in (2.5, 6.0, 7.5, 1.0)])
+        if args.fused:
+            bytes_per_cell, kernel = 14, "k_expr<2,2,2,0>: 8 operators over 3 u16 bands, one pass"
+            S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+            prog = [(ec.SUB, S(0), S(1), 0), (ec.MUL, R(0), K(0), 0),      # r0 = (nir - red) * 2.5
+                    (ec.MUL, S(1), K(1), 1), (ec.ADD, S(0), R(1), 1),      # r1 = nir + red * 6
+                    (ec.MUL, S(2), K(2), 2), (ec.SUB, R(1), R(2), 1),      # r1 = r1 - blue * 7.5
+                    (ec.ADD, R(1), K(3), 1), (ec.DIV, R(0), R(1), 0)]      # r0 = r0 / (r1 + 1)
+            st = (E.EcExprStep * len(prog))(*[E.EcExprStep(*q) for q in prog])
+            dt3 = (C.c_uint8 * 3)(ec.UInt16, ec.UInt16, ec.UInt16)
+            p3 = (C.c_void_p * 3)(nir.mem.ptr, red.mem.ptr, blue.mem.ptr)
+
+            def step():
+                chk(L.ec_expr(dt3, p3, 3, sc, 4, st, len(prog), n, out.mem.ptr, stream))
+        else:
+            # the reference's eager evaluation: every operator one pass over f64 temporaries
+            t = [ec.CellBuffer.empty(n, ec.Float64) for _ in range(7)]  # one temporary per operator, as the reference allocates
+            bytes_per_cell = (2 + 2 + 8) + (8 + 8) + (2 + 8) + (2 + 8 + 8) + (2 + 8) + (8 + 8 + 8) + (8 + 8) + (8 + 8 + 8)  # 136
+            kernel = "k_binop_direct / k_binop_scalar x 8 (f64 temporaries): eager, 8 passes"
+            U16, F64 = ec.UInt16, ec.Float64
+
+            def step():
+                chk(L.ec_binop(ec.SUB, U16, nir.mem.ptr, U16, red.mem.ptr, n, t[0].mem.ptr, stream))
+                chk(L.ec_binop_scalar(ec.MUL, F64, t[0].mem.ptr, n, C.byref(sc[0]), t[1].mem.ptr, stream))
+                chk(L.ec_binop_scalar(ec.MUL, U16, red.mem.ptr, n, C.byref(sc[1]), t[2].mem.ptr, stream))
+                chk(L.ec_binop(ec.ADD, U16, nir.mem.ptr, F64, t[2].mem.ptr, n, t[3].mem.ptr, stream))
+                chk(L.ec_binop_scalar(ec.MUL, U16, blue.mem.ptr, n, C.byref(sc[2]), t[4].mem.ptr, stream))
+                chk(L.ec_binop(ec.SUB, F64, t[3].mem.ptr, F64, t[4].mem.ptr, n, t[5].mem.ptr, stream))
+                chk(L.ec_binop_scalar(ec.ADD, F64, t[5].mem.ptr, n, C.byref(sc[3]), t[6].mem.ptr, stream))
+                chk(L.ec_binop(ec.DIV, F64, t[1].mem.ptr, F64, t[6].mem.ptr, n, out.mem.ptr, stream))
+        wl = f"{side}x{side} u16 EVI 2.5(nir-red)/(nir+6red-7.5blue+1), 8 operators, " + ("one pass (ec_expr)" if args.fused else "eager")
     else:
         a = ec.CellBuffer.empty(n, ec.UInt16)
         chk(L.ec_synth_fill(ec.UInt16, a.mem.ptr, n, 0x5EED0006, off, 1.0, 65534.0, stream))

@@ -1,0 +1,131 @@
+// ec_expr.hip — ABI entry points of the expression-program kernel (ec_expr.hpp): validation of a program, register
+// liveness, operand set-up and dispatch by the streams' byte widths.
+#include <hip/hip_runtime.h>
+
+#include "ec_expr.hpp"
+#include "ec_lattice.hpp"
+#include "ec_runtime.hpp"
+
+using namespace ecd;
+
+static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n_streams, const uint8_t* const* masks,
+                             const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
+                             double* out, uint8_t* out_mask, hipStream_t s, const char* what) {
+    if (n_streams < 1 || n_streams > kExprMaxStreams) return set_error(EC_ERR_ARG, "%s: %d operand streams (1..%d)", what, int(n_streams), kExprMaxStreams);
+    if (n_scalars < 0 || n_scalars > kExprMaxScalars) return set_error(EC_ERR_ARG, "%s: %d scalars (0..%d)", what, int(n_scalars), kExprMaxScalars);
+    if (n_steps < 1 || n_steps > kExprMaxSteps) return set_error(EC_ERR_ARG, "%s: %d steps (1..%d)", what, int(n_steps), kExprMaxSteps);
+    if (!dt || !p || !steps || !out || (n_scalars > 0 && !scalars)) return set_error(EC_ERR_ARG, "%s: null pointer", what);
+    ExprArgs ea{};
+    bool aligned = aligned_to(out, 16);
+    for (int k = 0; k < n_streams; ++k) {
+        if (!ecl::valid(dt[k])) return set_error(EC_ERR_UNSUPPORTED_TYPE, "%s: bad dtype of stream %d", what, k);
+        if (!p[k]) return set_error(EC_ERR_ARG, "%s: stream %d is null", what, k);
+        ea.p[k] = p[k];
+        ea.dt[k] = static_cast<int8_t>(dt[k]);
+        aligned = aligned && aligned_to(p[k], 16);
+    }
+    for (int k = n_streams; k < kExprMaxStreams; ++k) ea.p[k] = p[0];  // never read (class 0)
+    for (int k = 0; k < n_scalars; ++k) {
+        if (!ecl::valid(scalars[k].dtype)) return set_error(EC_ERR_ARG, "%s: bad dtype of scalar %d", what, k);
+        ea.sc[k] = ec_value_to_f64(&scalars[k]);  // impl $trt<R: Into<CellValue>> (src/buffer.rs:346-352): widened once, here
+    }
+    bool written[kExprRegs] = {false, false, false, false};
+    for (int k = 0; k < n_steps; ++k) {
+        const ec_expr_step& st = steps[k];
+        if (st.op < EC_ADD || st.op > EC_DIV) return set_error(EC_ERR_ARG, "%s: step %d: bad op", what, k);
+        if (st.dst < 0 || st.dst >= kExprRegs) return set_error(EC_ERR_ARG, "%s: step %d: destination register %d (0..%d)", what, k, int(st.dst), kExprRegs - 1);
+        for (int side = 0; side < 2; ++side) {
+            const int ref = side ? st.b : st.a;
+            bool ok = false;
+            if (ref >= kRefStream0 && ref < kRefReg0) ok = ref - kRefStream0 < n_streams;
+            else if (ref >= kRefReg0 && ref < kRefScalar0) ok = written[ref - kRefReg0];  // a register is read only after a step wrote it
+            else if (ref >= kRefScalar0 && ref < kRefEnd) ok = ref - kRefScalar0 < n_scalars;
+            if (!ok) return set_error(EC_ERR_ARG, "%s: step %d: operand %c refers to %d — no such stream / scalar, or a register no earlier step wrote",
+                                      what, k, side ? 'b' : 'a', ref);
+        }
+        written[st.dst] = true;
+    }
+    // Marks for the kernel (ec_expr.hpp expr_run): an operand that names the register the previous step wrote is read from
+    // the accumulator; a result that only such an operand (or nothing) reads before the register is overwritten is not filed.
+    for (int k = 0; k < n_steps; ++k) {
+        const ec_expr_step& st = steps[k];
+        uint64_t w = uint64_t(st.op) | uint64_t(st.dst) << 2 | uint64_t(st.a) << 4 | uint64_t(st.b) << 8;
+        if (k > 0) {
+            const int prev = kRefReg0 + steps[k - 1].dst;
+            if (st.a == prev) w |= kStepAAcc;
+            if (st.b == prev) w |= kStepBAcc;
+        }
+        bool read_later = false;
+        for (int j = k + 1; j < n_steps && !read_later; ++j) {
+            const int me = kRefReg0 + st.dst;
+            if (j > k + 1 && (steps[j].a == me || steps[j].b == me)) read_later = true;
+            if (steps[j].dst == st.dst) break;  // overwritten (after step j's own reads)
+        }
+        if (!read_later) w |= kStepNoFile;
+        ea.prog[k >> 2] |= w << (16 * (k & 3));
+    }
+    ea.nstreams = static_cast<int8_t>(n_streams);
+    ea.nsteps = static_cast<int8_t>(n_steps);
+    if (masks) {
+        if (!out_mask) return set_error(EC_ERR_ARG, "%s: null out_mask", what);
+        aligned = aligned && aligned_to(out_mask, 16);
+        for (int k = 0; k < n_streams; ++k) {
+            if (!masks[k]) return set_error(EC_ERR_ARG, "%s: null mask %d", what, k);
+            bool seen = false;
+            for (int j = 0; j < ea.nmask; ++j) seen = seen || ea.m[j] == masks[k];
+            if (!seen) {
+                ea.m[ea.nmask++] = masks[k];
+                aligned = aligned && aligned_to(masks[k], 16);
+            }
+        }
+    }
+    if (!aligned) {
+        k_expr_cellwise<0><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(ea, out, out_mask, n);
+        return check_launch("expr(cellwise)");
+    }
+    // peel one leading cell when that puts more of the 1-byte streams on even addresses (peel_head's rule)
+    unsigned c0 = 0, c1 = 0;
+    size_t stream_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0}, narrowest = 8;
+    int cls[kExprMaxStreams] = {0, 0, 0, 0};
+    for (int k = 0; k < n_streams; ++k) {
+        const size_t bytes = ecl::size_of(dt[k]);
+        c0 += peel_cost(p[k], bytes, 0);
+        c1 += peel_cost(p[k], bytes, 1);
+        cls[k] = fused_class_index(bytes);
+        stream_bytes[k] = n * bytes;
+        if (bytes < narrowest) narrowest = bytes;
+    }
+    for (int j = 0; j < ea.nmask; ++j) stream_bytes[4 + j] = n;
+    ea.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
+    ea.cacheable = static_cast<uint8_t>(cache_plan(stream_bytes, 8));
+    const size_t per_tile = size_t(kBlock) * kExprU;
+    const unsigned grid = grid_for((((n - ea.head) >> 1) + per_tile - 1) / per_tile);
+    ExprKernel kern = nullptr;
+    switch (cls[0]) {
+        case 1: kern = expr_kernel<1>(cls[1], cls[2], cls[3]); break;
+        case 2: kern = expr_kernel<2>(cls[1], cls[2], cls[3]); break;
+        case 3: kern = expr_kernel<4>(cls[1], cls[2], cls[3]); break;
+        default: kern = expr_kernel<8>(cls[1], cls[2], cls[3]); break;
+    }
+    if (!kern) return set_error(EC_ERR_ARG, "%s: no kernel for stream classes %d %d %d %d", what, cls[0], cls[1], cls[2], cls[3]);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, ea, out, out_mask, n);
+    return check_launch("expr");
+}
+
+extern "C" ec_status ec_expr(const ec_dtype* dt, const void* const* p, int32_t n_streams, const ec_value* scalars, int32_t n_scalars,
+                             const ec_expr_step* steps, int32_t n_steps, size_t n, double* out, ec_stream stream) {
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    if (n == 0) return EC_OK;
+    return launch_expr(dt, p, n_streams, nullptr, scalars, n_scalars, steps, n_steps, n, out, nullptr, static_cast<hipStream_t>(stream), "ec_expr");
+}
+
+extern "C" ec_status ec_masked_expr(const ec_dtype* dt, const void* const* p, const uint8_t* const* masks, int32_t n_streams,
+                                    const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
+                                    double* out, uint8_t* out_mask, ec_stream stream) {
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    if (n == 0) return EC_OK;
+    if (!masks) return set_error(EC_ERR_ARG, "ec_masked_expr: null masks");
+    return launch_expr(dt, p, n_streams, masks, scalars, n_scalars, steps, n_steps, n, out, out_mask, static_cast<hipStream_t>(stream), "ec_masked_expr");
+}

@@ -813,6 +813,59 @@ template <typename B> inline B eval(const ScalarTree<B>& t) { return expr(*t.l.l
 template <typename B> inline B eval(const Node<B>& n) { return n.l->binop(n.op, *n.r); }
 template <typename B> inline B eval(const Tree<B>& t) { return expr(*t.l.l, t.l.op, *t.l.r, t.op, *t.rl, t.rop, t.rr); }
 
+
+// An operator tree of ANY depth in one pass (ec_expr): up to four buffers of any cell types, eight scalars, sixteen steps
+// `reg[dst] = a op b` over four f64 registers; the value is what the last step computed.  Same bits as the eager
+// evaluation of the same operators in the same order.  EVI, 2.5 (nir - red) / (nir + 6 red - 7.5 blue + 1):
+//   using namespace ec::fused;
+//   auto evi = program({&nir, &red, &blue}, {2.5, 6.0, 7.5, 1.0},
+//                      {{EC_SUB, stream(0), stream(1), 0}, {EC_MUL, reg(0), scalar(0), 0}, {EC_MUL, stream(1), scalar(1), 1},
+//                       {EC_ADD, stream(0), reg(1), 1},    {EC_MUL, stream(2), scalar(2), 2}, {EC_SUB, reg(1), reg(2), 1},
+//                       {EC_ADD, reg(1), scalar(3), 1},    {EC_DIV, reg(0), reg(1), 0}});
+// A malformed program (bad reference, register read before written, counts out of range) throws Error (EC_ERR_ARG).
+constexpr int8_t stream(int k) { return EC_EXPR_STREAM(k); }
+constexpr int8_t reg(int k) { return EC_EXPR_REG(k); }
+constexpr int8_t scalar(int k) { return EC_EXPR_SCALAR(k); }
+inline CellBuffer program(const std::vector<const CellBuffer*>& streams, const std::vector<CellValue>& scalars,
+                          const std::vector<ec_expr_step>& steps) {
+    size_t n = streams.empty() ? 0 : streams[0]->len();
+    std::vector<ec_dtype> dt;
+    std::vector<const void*> p;
+    for (const CellBuffer* b : streams) {
+        n = std::min(n, b->len());
+        dt.push_back(static_cast<ec_dtype>(b->cell_type()));
+        p.push_back(b->ptr());
+    }
+    if (n == 0) return CellBuffer(CellType::UInt8, 0);
+    std::vector<ec_value> sc;
+    for (const CellValue& v : scalars) sc.push_back(v.raw());
+    CellBuffer out(CellType::Float64, n);
+    check(ec_expr(dt.data(), p.data(), static_cast<int32_t>(streams.size()), sc.data(), static_cast<int32_t>(sc.size()), steps.data(),
+                  static_cast<int32_t>(steps.size()), n, static_cast<double*>(out.ptr()), current_stream()));
+    return out;
+}
+inline MaskedCellBuffer program(const std::vector<const MaskedCellBuffer*>& streams, const std::vector<CellValue>& scalars,
+                                const std::vector<ec_expr_step>& steps) {
+    size_t n = streams.empty() ? 0 : streams[0]->len();
+    std::vector<ec_dtype> dt;
+    std::vector<const void*> p;
+    std::vector<const uint8_t*> m;
+    for (const MaskedCellBuffer* b : streams) {
+        n = std::min(n, b->len());
+        dt.push_back(static_cast<ec_dtype>(b->cell_type()));
+        p.push_back(b->buffer().ptr());
+        m.push_back(b->mask().ptr());
+    }
+    if (n == 0) return MaskedCellBuffer(CellBuffer(CellType::UInt8, 0), Mask(0));
+    std::vector<ec_value> sc;
+    for (const CellValue& v : scalars) sc.push_back(v.raw());
+    CellBuffer out(CellType::Float64, n);
+    Mask om(n);
+    check(ec_masked_expr(dt.data(), p.data(), m.data(), static_cast<int32_t>(streams.size()), sc.data(), static_cast<int32_t>(sc.size()),
+                         steps.data(), static_cast<int32_t>(steps.size()), n, static_cast<double*>(out.ptr()), om.ptr(), current_stream()));
+    return MaskedCellBuffer(std::move(out), std::move(om));
+}
+
 }  // namespace fused
 
 // ---------------------------------------------------------------- one process, all GPUs of the node

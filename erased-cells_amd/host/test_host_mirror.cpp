@@ -418,6 +418,19 @@ static void gdal_tests(const std::string& data_dir) {
         MaskedCellBuffer mf = fused::eval((lazy(mnir) - lazy(mred)) / (lazy(mnir) + lazy(mred)));
         CHECK(mf == (mnir - mred) / (mnir + mred) && mf.counts().second == 4);
         CHECK(fused::eval((lazy(mnir) + lazy(mred)) * 2.0) == (mnir + mred) * 2.0);
+        // a tree deeper than two levels as ONE pass (ec_expr): EVI with the red band standing in for blue
+        using namespace fused;
+        const std::vector<ec_expr_step> evi = {{EC_SUB, stream(0), stream(1), 0}, {EC_MUL, reg(0), scalar(0), 0},
+                                               {EC_MUL, stream(1), scalar(1), 1}, {EC_ADD, stream(0), reg(1), 1},
+                                               {EC_MUL, stream(2), scalar(2), 2}, {EC_SUB, reg(1), reg(2), 1},
+                                               {EC_ADD, reg(1), scalar(3), 1},    {EC_DIV, reg(0), reg(1), 0}};
+        const std::vector<CellValue> k = {2.5, 6.0, 7.5, 1.0};
+        CellBuffer evi_eager = ((nir - red) * 2.5) / (((nir + red * 6.0) - r32 * 7.5) + 1.0);
+        CHECK(program(std::vector<const CellBuffer*>{&nir, &red, &r32}, k, evi) == evi_eager);
+        MaskedCellBuffer mr32 = mred.convert(CellType::Float32);
+        MaskedCellBuffer mevi = program(std::vector<const MaskedCellBuffer*>{&mnir, &mred, &mr32}, k, evi);
+        CHECK(mevi == ((mnir - mred) * 2.5) / (((mnir + mred * 6.0) - mr32 * 7.5) + 1.0));
+        CHECK_THROWS(Error, program(std::vector<const CellBuffer*>{&nir}, k, {{EC_ADD, stream(0), reg(0), 0}}));  // register read before written
     }
     // GdalND -> NoData<T> (src/gdal/mod.rs:49-70): range-checked
     CHECK(!nodata_from_f64<uint16_t>(std::nullopt, "u16").value().has_value());

@@ -30,6 +30,11 @@ class EcValue(C.Structure):
     _fields_ = [("dtype", C.c_uint8), ("pad_", C.c_uint8 * 7), ("v", _Payload)]
 
 
+class EcExprStep(C.Structure):
+    """ec_expr_step: reg[dst] = a op b (include/erased_cells.h)."""
+    _fields_ = [("op", C.c_int8), ("a", C.c_int8), ("b", C.c_int8), ("dst", C.c_int8)]
+
+
 VP, SZ, I32, U8P = C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p
 PV = C.POINTER(EcValue)
 PVP, PSZ = C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)
@@ -82,6 +87,8 @@ SIGNATURES = {
     "ec_masked_binop": (I32, [I32, C.c_uint8, VP, U8P, C.c_uint8, VP, U8P, SZ, VP, U8P, VP]),
     "ec_fused": (I32, [I32, I32, I32, C.POINTER(C.c_uint8), C.POINTER(VP), PV, SZ, VP, VP]),
     "ec_masked_fused": (I32, [I32, I32, I32, C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(VP), PV, SZ, VP, U8P, VP]),
+    "ec_expr": (I32, [C.POINTER(C.c_uint8), C.POINTER(VP), I32, PV, I32, C.POINTER(EcExprStep), I32, SZ, VP, VP]),
+    "ec_masked_expr": (I32, [C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(VP), I32, PV, I32, C.POINTER(EcExprStep), I32, SZ, VP, U8P, VP]),
     "ec_neg": (I32, [C.c_uint8, VP, SZ, VP, VP]),
     "ec_convert": (I32, [C.c_uint8, VP, C.c_uint8, VP, SZ, VP]),
     "ec_fill": (I32, [C.c_uint8, VP, SZ, PV, VP]),

@@ -61,15 +61,110 @@ def add_mul(a, b, c):
     return expr(a, B.ADD, b, B.MUL, c)
 
 
+STREAM0, REG0, SCALAR0 = 0, 4, 8  # operand references of a program step (EC_EXPR_STREAM / _REG / _SCALAR)
+MAX_STREAMS, REGS, MAX_SCALARS, MAX_STEPS = 4, 4, 8, 16
+
+
+def program(streams, scalars, steps):
+    """Run an expression PROGRAM in one pass (`ec_expr` / `ec_masked_expr`): `streams` up to four buffers (all plain or
+    all masked), `scalars` up to eight numbers, `steps` a list of `(op, a, b, dst)` with `a`, `b` references
+    (`STREAM0 + k`, `REG0 + k`, `SCALAR0 + k`) and `dst` a register 0..3; the value of the program is what its last step
+    computed.  Bit-identical to evaluating the same operators one by one."""
+    assert 1 <= len(streams) <= MAX_STREAMS and len(scalars) <= MAX_SCALARS and 1 <= len(steps) <= MAX_STEPS
+    masked = isinstance(streams[0], B.MaskedCellBuffer)
+    assert all(isinstance(o, B.MaskedCellBuffer) == masked for o in streams), "mix of masked and plain operands"
+    bufs = [o.buffer() if masked else o for o in streams]
+    k = len(streams)
+    dt = (C.c_uint8 * k)(*[b.ct for b in bufs])
+    p = (C.c_void_p * k)(*[b.mem.ptr for b in bufs])
+    sc = (B.EcValue * max(1, len(scalars)))(*[B.CellValue.new(x).to_ec() for x in scalars])
+    from ._ffi import EcExprStep
+    st = (EcExprStep * len(steps))(*[EcExprStep(*s_) for s_ in steps])
+    n = min(b.len() for b in bufs)
+    if n == 0:
+        e = B.CellBuffer.empty(0, B.UInt8)
+        return B.MaskedCellBuffer(e, B.Mask.empty(0)) if masked else e
+    out = B.CellBuffer.empty(n, B.Float64)
+    if not masked:
+        check(lib().ec_expr(dt, p, k, sc, len(scalars), st, len(steps), n, out.mem.ptr, B.stream()))
+        return out
+    m = (C.c_void_p * k)(*[o.mask().mem.ptr for o in streams])
+    om = B.Mask.empty(n)
+    check(lib().ec_masked_expr(dt, p, m, k, sc, len(scalars), st, len(steps), n, out.mem.ptr, om.mem.ptr, B.stream()))
+    return B.MaskedCellBuffer(out, om)
+
+
+class _Compiler:
+    """Schedules an operator tree onto the four registers of `ec_expr`: post-order, the sub-tree that needs more
+    registers first (Sethi-Ullman), a register freed as soon as its value has been consumed.  `compile` returns None when
+    the tree does not fit (more than 4 distinct buffers, 8 scalars, 16 operators or 4 live temporaries)."""
+
+    def __init__(self):
+        self.streams, self.scalars, self.steps, self.free = [], [], [], [0, 1, 2, 3]
+
+    def _leaf(self, x):
+        if _is_buf(x):
+            b = x.buffer() if isinstance(x, B.MaskedCellBuffer) else x
+            for i, s_ in enumerate(self.streams):
+                t = s_.buffer() if isinstance(s_, B.MaskedCellBuffer) else s_
+                same_mask = (not isinstance(x, B.MaskedCellBuffer)) or s_.mask().mem.ptr == x.mask().mem.ptr
+                if t.mem.ptr == b.mem.ptr and t.ct == b.ct and t.len() == b.len() and same_mask:
+                    return STREAM0 + i
+            if len(self.streams) == MAX_STREAMS:
+                raise OverflowError
+            self.streams.append(x)
+            return STREAM0 + len(self.streams) - 1
+        if len(self.scalars) == MAX_SCALARS:
+            raise OverflowError
+        self.scalars.append(x)
+        return SCALAR0 + len(self.scalars) - 1
+
+    @staticmethod
+    def _need(t) -> int:  # registers needed to evaluate the sub-tree
+        if t.op is None:
+            return 0
+        l, r = _Compiler._need(t.l), _Compiler._need(t.r)
+        return max(1, l, r) if l != r else l + 1 if l else 1
+
+    def _emit(self, t):
+        if t.op is None:
+            return self._leaf(t.leaf)
+        first_right = self._need(t.r) > self._need(t.l)
+        if first_right:
+            rb = self._emit(t.r)
+            ra = self._emit(t.l)
+        else:
+            ra = self._emit(t.l)
+            rb = self._emit(t.r)
+        for ref in (ra, rb):  # operands that are registers are dead after this step
+            if REG0 <= ref < SCALAR0 and ref - REG0 not in self.free:
+                self.free.append(ref - REG0)
+        if not self.free or len(self.steps) == MAX_STEPS:
+            raise OverflowError
+        dst = min(self.free)
+        self.free.remove(dst)
+        self.steps.append((t.op, ra, rb, dst))
+        return REG0 + dst
+
+    def compile(self, tree):
+        try:
+            self._emit(tree)
+        except OverflowError:
+            return None
+        return self.streams, self.scalars, self.steps
+
+
 class Lazy:
     """Operator syntax that defers evaluation, so a chain written the reference's way runs fused:
 
         n, r = lazy(nir), lazy(red)
         ndvi = ((n - r) / (n + r)).eval()        # one pass, bit-identical to (nir - red) / (nir + red)
 
-    A tree is evaluated bottom-up; wherever a node's children are at most one operator deep — `(x o1 y) o2 z`,
-    `(x o1 y) o2 (z o3 w)` — that node runs as one fused launch, deeper sub-trees are evaluated first (each
-    again fused as far as it goes).  Leaves are buffers (all plain or all masked) or scalars.
+    A tree of up to two levels — `(x o1 y) o2 z`, `(x o1 y) o2 (z o3 w)` — runs as one launch of the two-level kernel.
+    A deeper tree runs as ONE launch of the expression-program kernel (`ec_expr`) when it has at most 4 distinct
+    buffers, 8 scalars, 16 operators and can be scheduled onto 4 temporaries (EVI: 3 bands, 4 scalars, 8 operators, 2
+    temporaries); only trees beyond that are cut: their deeper sub-trees are evaluated first, each again fused as far as
+    it goes.  Leaves are buffers (all plain or all masked) or scalars.
     The C++ mirror has the same as expression templates (`lazy()`, host/erased_cells.hpp)."""
 
     __slots__ = ("op", "l", "r", "leaf")
@@ -101,9 +196,19 @@ class Lazy:
         """This sub-tree as a leaf (evaluating it if it is not one already)."""
         return self if self.op is None else Lazy(leaf=self.eval())
 
+    def _has_buffer(self) -> bool:
+        return _is_buf(self.leaf) if self.op is None else (self.l._has_buffer() or self.r._has_buffer())
+
     def eval(self):
         if self.op is None:
             return self.leaf
+        two_level = self._depth() == 2 and self.l.op is not None   # (x o1 y) o2 z  or  (x o1 y) o2 (z o3 w)
+        if self._depth() >= 2 and not two_level and self._has_buffer():
+            # not a shape of the two-level kernel (deeper, or `z o2 (x o1 y)`): one pass through the expression-program
+            # kernel if the tree can be scheduled onto its four registers; otherwise the pieces below, deeper sub-trees first
+            prog = _Compiler().compile(self)
+            if prog is not None and prog[0]:
+                return program(*prog)
         l = self.l if self.l._depth() <= 1 else self.l._flat()
         r = self.r if self.r._depth() <= 1 else self.r._flat()
         if l.op is None and r.op is None:           # x o y

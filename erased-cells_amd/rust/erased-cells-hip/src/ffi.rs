@@ -44,6 +44,30 @@ pub struct ec_value {
     pub bits: u64, // the C union; read/written through to_bits()/from_bits() of the primitive
 }
 
+/// One step of an expression program (`ec_expr`): `reg[dst] = a op b`; `a`, `b` are operand references
+/// (`ec_expr_stream(k)`, `ec_expr_reg(k)`, `ec_expr_scalar(k)`).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct ec_expr_step {
+    pub op: i8,
+    pub a: i8,
+    pub b: i8,
+    pub dst: i8,
+}
+pub const fn ec_expr_stream(k: i8) -> i8 {
+    k
+}
+pub const fn ec_expr_reg(k: i8) -> i8 {
+    4 + k
+}
+pub const fn ec_expr_scalar(k: i8) -> i8 {
+    8 + k
+}
+pub const EC_EXPR_MAX_STREAMS: usize = 4;
+pub const EC_EXPR_REGS: usize = 4;
+pub const EC_EXPR_MAX_SCALARS: usize = 8;
+pub const EC_EXPR_MAX_STEPS: usize = 16;
+
 extern "C" {
     pub fn ec_abi_version() -> i32;
     pub fn ec_init(device: i32) -> ec_status;
@@ -114,6 +138,11 @@ extern "C" {
     pub fn ec_masked_fused(o1: ec_op, o2: ec_op, o3: ec_op, dt: *const ec_dtype, p: *const *const c_void,
                            masks: *const *const u8, scalars_or_null: *const ec_value, n: usize, out: *mut f64,
                            out_mask: *mut u8, s: ec_stream) -> ec_status;
+    pub fn ec_expr(dt: *const ec_dtype, p: *const *const c_void, n_streams: i32, scalars: *const ec_value, n_scalars: i32,
+                   steps: *const ec_expr_step, n_steps: i32, n: usize, out: *mut f64, s: ec_stream) -> ec_status;
+    pub fn ec_masked_expr(dt: *const ec_dtype, p: *const *const c_void, masks: *const *const u8, n_streams: i32,
+                          scalars: *const ec_value, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32, n: usize,
+                          out: *mut f64, out_mask: *mut u8, s: ec_stream) -> ec_status;
     pub fn ec_comm_get_unique_id(uid: *mut ec_comm_uid) -> ec_status;
     pub fn ec_comm_init_rank(uid: *const ec_comm_uid, n_ranks: i32, rank: i32, comm: *mut ec_comm) -> ec_status;
     pub fn ec_comm_init_all(devices: *const i32, n: i32, comms: *mut ec_comm) -> ec_status;

@@ -93,3 +93,86 @@ pub fn ndvi_masked(nir: &MaskedCellBuffer, red: &MaskedCellBuffer) -> MaskedCell
     );
     MaskedCellBuffer::new(out, om)
 }
+
+/// One step of an expression program: `reg[dst] = a op b`.  Operands are made with [`stream`](Step::stream),
+/// [`reg`](Step::reg), [`scalar`](Step::scalar).
+pub type Step = ec_expr_step;
+
+impl Step {
+    pub const fn new(op: ec_op, a: i8, b: i8, dst: i8) -> Self {
+        Step { op: op as i8, a, b, dst }
+    }
+    /// Operand: buffer `k` (0..=3) of the call.
+    pub const fn stream(k: i8) -> i8 {
+        ec_expr_stream(k)
+    }
+    /// Operand: register `k` (0..=3), written by an earlier step.
+    pub const fn reg(k: i8) -> i8 {
+        ec_expr_reg(k)
+    }
+    /// Operand: scalar `k` (0..=7) of the call.
+    pub const fn scalar(k: i8) -> i8 {
+        ec_expr_scalar(k)
+    }
+}
+
+/// An operator tree of any depth in ONE pass (`ec_expr`): up to four buffers of any cell types, up to eight scalars,
+/// up to sixteen steps over four f64 registers; the value is what the last step computed.  Same bits as the reference's
+/// eager evaluation of the same operators in the same order (every intermediate is an f64 rounded once, src/value.rs:207).
+/// EVI, `2.5 * (nir - red) / (nir + 6 * red - 7.5 * blue + 1)`:
+/// ```ignore
+/// use erased_cells::fused::{program, Step as S};
+/// use erased_cells::ffi::{EC_ADD, EC_DIV, EC_MUL, EC_SUB};
+/// let evi = program(&[&nir, &red, &blue], &[2.5.into(), 6.0.into(), 7.5.into(), 1.0.into()], &[
+///     S::new(EC_SUB, S::stream(0), S::stream(1), 0), S::new(EC_MUL, S::reg(0), S::scalar(0), 0),
+///     S::new(EC_MUL, S::stream(1), S::scalar(1), 1), S::new(EC_ADD, S::stream(0), S::reg(1), 1),
+///     S::new(EC_MUL, S::stream(2), S::scalar(2), 2), S::new(EC_SUB, S::reg(1), S::reg(2), 1),
+///     S::new(EC_ADD, S::reg(1), S::scalar(3), 1), S::new(EC_DIV, S::reg(0), S::reg(1), 0)]);
+/// ```
+///
+/// # Panics
+/// On a malformed program (the library's `EC_ERR_ARG`: a bad reference, a register read before it is written, counts
+/// out of range).
+pub fn program(streams: &[&CellBuffer], scalars: &[CellValue], steps: &[Step]) -> CellBuffer {
+    assert!(!streams.is_empty() && streams.len() <= EC_EXPR_MAX_STREAMS, "1..=4 buffers");
+    let n = streams.iter().map(|b| b.len()).min().unwrap_or(0);
+    if n == 0 {
+        return CellBuffer::empty_u8();
+    }
+    let dt: Vec<u8> = streams.iter().map(|b| b.cell_type() as u8).collect();
+    let p: Vec<*const c_void> = streams.iter().map(|b| b.dev_ptr()).collect();
+    let sc: Vec<ec_value> = scalars.iter().map(|v| v.to_ffi()).collect();
+    let out = CellBuffer::uninit(CellType::Float64, n);
+    must(
+        unsafe {
+            ec_expr(dt.as_ptr(), p.as_ptr(), streams.len() as i32, sc.as_ptr(), sc.len() as i32, steps.as_ptr(), steps.len() as i32, n,
+                    out.mem.ptr() as *mut f64, stream())
+        },
+        "ec_expr",
+    );
+    out
+}
+
+/// The masked form of [`program`]: values over all cells, mask = AND of the streams' masks (what the eager chain of
+/// `impl $trt for &MaskedCellBuffer`, src/masked/masked_buffer.rs:326-364, leaves behind).
+#[cfg(feature = "masked")]
+pub fn program_masked(streams: &[&MaskedCellBuffer], scalars: &[CellValue], steps: &[Step]) -> MaskedCellBuffer {
+    assert!(!streams.is_empty() && streams.len() <= EC_EXPR_MAX_STREAMS, "1..=4 buffers");
+    let n = streams.iter().map(|b| b.len()).min().unwrap_or(0);
+    if n == 0 {
+        return MaskedCellBuffer::new(CellBuffer::empty_u8(), Mask::uninit(0));
+    }
+    let dt: Vec<u8> = streams.iter().map(|b| b.cell_type() as u8).collect();
+    let p: Vec<*const c_void> = streams.iter().map(|b| b.buffer().dev_ptr()).collect();
+    let m: Vec<*const u8> = streams.iter().map(|b| b.mask().dev_ptr()).collect();
+    let sc: Vec<ec_value> = scalars.iter().map(|v| v.to_ffi()).collect();
+    let (out, om) = (CellBuffer::uninit(CellType::Float64, n), Mask::uninit(n));
+    must(
+        unsafe {
+            ec_masked_expr(dt.as_ptr(), p.as_ptr(), m.as_ptr(), streams.len() as i32, sc.as_ptr(), sc.len() as i32, steps.as_ptr(),
+                           steps.len() as i32, n, out.mem.ptr() as *mut f64, om.dev_ptr_mut(), stream())
+        },
+        "ec_masked_expr",
+    );
+    MaskedCellBuffer::new(out, om)
+}

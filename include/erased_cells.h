@@ -195,6 +195,34 @@ ec_status ec_masked_fused(ec_op o1, ec_op o2, ec_op o3, const ec_dtype dt[4], co
                           const uint8_t *const masks[4], const ec_value *scalars_or_null, size_t n,
                           double *out, uint8_t *out_mask, ec_stream stream);
 
+/* Expression programs (beyond two levels): a whole operator tree over up to four buffers in ONE pass.
+ * The reference evaluates `2.5 * (nir - red) / (nir + 6.0 * red - 7.5 * blue + 1.0)` operator by operator, a pass and an
+ * f64 temporary each (impl $trt for &CellBuffer / for CellBuffer with a scalar, src/buffer.rs:324-352); here the same
+ * operators run in the same order on registers, every step the same correctly rounded f64 op, so the result is
+ * bit-identical to the eager evaluation.  A program is a list of steps `reg[dst] = a op b` over four registers; an
+ * operand refers to a stream (buffer k of the call), a register an earlier step wrote, or a scalar; the program's value
+ * is what its LAST step computed.  `n` is the shortest buffer's length (zip truncation at every step).  Streams may have
+ * any mix of cell types; no allocation, no synchronisation (graph-capturable).  EC_ERR_ARG for a malformed program
+ * (bad reference, a register read before it is written, counts out of range). */
+typedef struct ec_expr_step {
+    int8_t op;  /* EC_ADD .. EC_DIV */
+    int8_t a;   /* left operand:  EC_EXPR_STREAM(k) | EC_EXPR_REG(k) | EC_EXPR_SCALAR(k) */
+    int8_t b;   /* right operand */
+    int8_t dst; /* register 0..3 that receives the result */
+} ec_expr_step;
+#define EC_EXPR_STREAM(k) ((int8_t)(k))       /* k = 0..3: dt[k] / p[k] of the call */
+#define EC_EXPR_REG(k) ((int8_t)(4 + (k)))    /* k = 0..3 */
+#define EC_EXPR_SCALAR(k) ((int8_t)(8 + (k))) /* k = 0..7: scalars[k] */
+enum { EC_EXPR_MAX_STREAMS = 4, EC_EXPR_REGS = 4, EC_EXPR_MAX_SCALARS = 8, EC_EXPR_MAX_STEPS = 16 };
+ec_status ec_expr(const ec_dtype *dt, const void *const *p, int32_t n_streams, const ec_value *scalars,
+                  int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps, size_t n, double *out,
+                  ec_stream stream);
+/* The masked form: also out_mask = AND of the streams' masks, what the eager chain of impl $trt for &MaskedCellBuffer
+ * (src/masked/masked_buffer.rs:326-364) leaves behind (scalars carry no mask). */
+ec_status ec_masked_expr(const ec_dtype *dt, const void *const *p, const uint8_t *const *masks, int32_t n_streams,
+                         const ec_value *scalars, int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps,
+                         size_t n, double *out, uint8_t *out_mask, ec_stream stream);
+
 /* ---------------------------------------------------------------- *
  * min/max under the reference's total order (ints natural; floats total_cmp),
  * folded from (T::MAX, T::MIN) — src/buffer.rs:169-173, masked:

@@ -393,6 +393,163 @@ def test_every_kernel_family_with_every_load_non_temporal(ec, pool):
         L.ec_tune_set(b"mall_mb", 256)
 
 
+# ---------------------------------------------------------------- expression programs (ec_expr): trees of any depth in one pass
+def _oracle_program(streams, scalars, steps):
+    """The program evaluated step by step on the oracle's typed loops — the eager chain the reference would run — and the
+    cells whose NaN bits the reference leaves open (both operands NaN under a commutative op, carried forward)."""
+    n = min(len(s_) for s_ in streams)
+    val, loose = {}, {}
+    for k, s_ in enumerate(streams):
+        val[k], loose[k] = s_[:n], np.zeros(n, bool)
+    for k, c in enumerate(scalars):
+        val[8 + k], loose[8 + k] = np.full(n, float(c)), np.zeros(n, bool)  # a scalar is widened to f64 once, on the host
+    last = None
+    for op, a, b, dst in steps:
+        r = eco.f_binop(op, val[a], val[b])
+        lo = loose[a] | loose[b]
+        if op in (eco.ADD, eco.MUL):
+            with np.errstate(all="ignore"):
+                lo = lo | (np.isnan(val[a].astype(np.float64)) & np.isnan(val[b].astype(np.float64)))
+        val[4 + dst], loose[4 + dst] = r, lo
+        last = 4 + dst
+    return val[last], loose[last]
+
+
+def test_expr_every_stream_class_kernel(ec, pool):
+    """All 340 k_expr<C0,C1,C2,C3> kernels (stream byte widths, packed): a program that uses every stream, a scalar and
+    three registers, cell kinds and ops rotating — against the oracle's step-by-step evaluation; one allocation (the
+    result) per call."""
+    host, dev, _, _ = pool
+    P = ec.fused
+    tick = 0
+    for ns in (1, 2, 3, 4):
+        import itertools
+        for classes in itertools.product((1, 2, 4, 8), repeat=ns):
+            tick += 1
+            cts = [_BY_WIDTH[c][(tick + k) % len(_BY_WIDTH[c])] for k, c in enumerate(classes)]
+            bufs = [dev[ct].shard(k, N) for k, ct in enumerate(cts)]
+            hs = [host[ct][k:k + N] for k, ct in enumerate(cts)]
+            ops = [OPS[(tick + j) % 4] for j in range(6)]
+            steps = [(ops[0], P.STREAM0, P.SCALAR0, 0)]                                  # r0 = s0 op 2.5
+            for k in range(1, ns):
+                steps.append((ops[k], P.REG0 + (k - 1) % 3, P.STREAM0 + k, k % 3))     # r[k] = r[k-1] op s_k   (registers 0..2)
+            steps.append((ops[4], P.STREAM0 + ns - 1, P.REG0 + (ns - 1) % 3, 3))        # r3 = s_last op r
+            steps.append((ops[5], P.REG0 + 3, P.SCALAR0 + 1, (ns - 1) % 3))             # r = r3 op 7
+            before = _pool_allocs(ec)
+            got = P.program(bufs, [2.5, 7], steps)
+            assert _pool_allocs(ec) == before + 1
+            eo, loose = _oracle_program(hs, [2.5, 7], steps)
+            try:
+                assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+            except AssertionError as e:
+                raise AssertionError(f"classes {classes} types {cts} steps {steps}: {e}") from None
+
+
+def test_expr_random_programs_masks_windows_and_the_eager_chain(ec, pool):
+    """Random valid programs (1-4 streams of any types, 0-8 scalars, 1-16 steps, registers reused) over ragged lengths and
+    odd windows: against the oracle, and — where every scalar stands on the right, as the reference's operators require —
+    against the same operators run one by one through the eager HIP path; masked programs AND the streams' masks."""
+    host, dev, m, dm = pool
+    P = ec.fused
+    rng = np.random.default_rng(4321)
+    for trial in range(60):
+        ns = int(rng.integers(1, 5))
+        n, off = [(N, 0), (1, 0), (2, 1), (515, 1), (2049, 3)][trial % 5]
+        cts = [int(c) for c in rng.integers(0, NT, size=ns)]
+        bufs = [dev[ct].shard(off + k, n) for k, ct in enumerate(cts)]
+        hs = [host[ct][off + k:off + k + n] for k, ct in enumerate(cts)]
+        scalars = [float(x) for x in rng.choice([2.5, -3.0, 0.5, 7.0, 1e-3, 65536.0, -0.0, 1.0], size=int(rng.integers(0, 9)))]
+        written, steps = [], []
+        for _ in range(int(rng.integers(1, 17))):
+            def ref(left):
+                kinds = ["s"] + (["r"] if written else []) + (["c"] if scalars and not left else [])
+                kind = kinds[int(rng.integers(0, len(kinds)))]
+                if kind == "s":
+                    return P.STREAM0 + int(rng.integers(0, ns))
+                if kind == "r":
+                    return P.REG0 + int(rng.choice(written))
+                return P.SCALAR0 + int(rng.integers(0, len(scalars)))
+            dst = int(rng.integers(0, 4))
+            steps.append((int(rng.integers(0, 4)), ref(True), ref(False), dst))
+            if dst not in written:
+                written.append(dst)
+        got = P.program(bufs, scalars, steps)
+        eo, loose = _oracle_program(hs, scalars, steps)
+        assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+        # the eager chain on the device: every step one operator call
+        regs = {}
+        for op, a, b, dst in steps:
+            x = bufs[a] if a < 4 else regs[a - 4]
+            y = bufs[b] if b < 4 else regs[b - 4] if b < 8 else scalars[b - 8]
+            regs[dst] = x._binop(op, y)
+        eager = regs[steps[-1][3]].to_numpy()
+        assert_f64_bits_equal(got.to_numpy(), eager, nan_by_class_where=loose)
+        if trial % 3 == 0:  # masked: the result's mask is the AND of every stream's mask (used by the program or not)
+            mb = [ec.MaskedCellBuffer(b, dm[k % 2].shard(off + k, n)) for k, b in enumerate(bufs)]
+            gm = P.program(mb, scalars, steps)
+            assert_f64_bits_equal(gm.buffer().to_numpy(), eo, nan_by_class_where=loose)
+            want = np.ones(n, np.uint8)
+            for k in range(ns):
+                want &= m[k % 2][off + k:off + k + n]
+            assert np.array_equal(gm.mask().to_numpy(), want)
+
+
+def test_lazy_trees_deeper_than_two_levels_run_as_one_pass(ec, pool):
+    """`lazy()` operator syntax: EVI over three u16 bands (8 operators, 4 scalars) and a right-heavy tree are ONE launch
+    (one allocation: the result), bit-identical to the eager evaluation operator by operator; a tree that needs more than
+    four buffers is cut and still correct."""
+    host, dev, _, _ = pool
+    L = ec.fused.lazy
+    nir, red, blue = dev[eco.U16].shard(0, N), dev[eco.U16].shard(3, N), dev[eco.U16].shard(5, N)
+    before = _pool_allocs(ec)
+    evi = (((L(nir) - red) * 2.5) / (((L(nir) + L(red) * 6.0) - L(blue) * 7.5) + 1.0)).eval()
+    assert _pool_allocs(ec) == before + 1, "EVI must be one pass: no temporaries"
+    eager = ((nir - red) * 2.5) / (((nir + red * 6.0) - blue * 7.5) + 1.0)
+    assert np.array_equal(bits_of(evi.to_numpy()), bits_of(eager.to_numpy()))
+    hn, hr, hb = host[eco.U16][:N], host[eco.U16][3:3 + N], host[eco.U16][5:5 + N]
+    f = lambda op, a, b: eco.f_binop(op, a, b if isinstance(b, np.ndarray) else np.full(N, float(b)))  # noqa: E731
+    exp = f(eco.DIV, f(eco.MUL, f(eco.SUB, hn, hr), 2.5),
+            f(eco.ADD, f(eco.SUB, f(eco.ADD, hn, f(eco.MUL, hr, 6.0)), f(eco.MUL, hb, 7.5)), 1.0))
+    assert_f64_bits_equal(evi.to_numpy(), exp)  # integer bands: no NaN can arise before the divide, none is left open
+    # right-heavy two-operator tree: not a shape of the two-level kernel, one pass through the program kernel
+    a, b, c = dev[eco.F32].shard(0, N), dev[eco.I16].shard(1, N), dev[eco.U8].shard(2, N)
+    before = _pool_allocs(ec)
+    got = (L(a) - (L(b) * c)).eval()
+    assert _pool_allocs(ec) == before + 1
+    assert np.array_equal(bits_of(got.to_numpy()), bits_of((a - (b * c)).to_numpy()))
+    # five distinct buffers: does not fit the four streams -> cut into pieces, same bits
+    d, e = dev[eco.F64].shard(4, N), dev[eco.U32].shard(6, N)
+    got = (((L(a) + b) * c) - ((L(d) / e) + a)).eval()
+    assert np.array_equal(bits_of(got.to_numpy()), bits_of((((a + b) * c) - ((d / e) + a)).to_numpy()))
+
+
+def test_expr_rejects_malformed_programs(ec, pool):
+    host, dev, _, _ = pool
+    L, E = ec.lib(), ec._ffi
+    x = dev[eco.U16].shard(0, N)
+    out = ec.CellBuffer.empty(N, ec.Float64)
+    dt, p = (C.c_uint8 * 1)(eco.U16), (C.c_void_p * 1)(x.mem.ptr)
+    sc = (E.EcValue * 1)(ec.CellValue.new(2.0).to_ec())
+
+    def run(steps, n_streams=1, n_scalars=1):
+        st = (E.EcExprStep * max(1, len(steps)))(*[E.EcExprStep(*s_) for s_ in steps])
+        return L.ec_expr(dt, p, n_streams, sc, n_scalars, st, len(steps), N, out.mem.ptr, ec.stream())
+
+    assert run([(eco.ADD, 0, 8, 0)]) == E.EC_OK
+    assert run([(eco.ADD, 0, 4, 0)]) == E.EC_ERR_ARG          # register 0 read before any step wrote it
+    assert run([(eco.ADD, 1, 8, 0)]) == E.EC_ERR_ARG          # stream 1 of a one-stream call
+    assert run([(eco.ADD, 0, 9, 0)]) == E.EC_ERR_ARG          # scalar 1 of one
+    assert run([(eco.ADD, 0, 8, 4)]) == E.EC_ERR_ARG          # register 4
+    assert run([(7, 0, 8, 0)]) == E.EC_ERR_ARG                # op
+    assert run([]) == E.EC_ERR_ARG
+    assert run([(eco.ADD, 0, 8, 0)] * 17) == E.EC_ERR_ARG
+    assert run([(eco.ADD, 0, 8, 0)], n_streams=5) == E.EC_ERR_ARG
+    assert run([(eco.ADD, 0, 8, 0)], n_scalars=9) == E.EC_ERR_ARG
+    bad_dt = (C.c_uint8 * 1)(10)
+    st = (E.EcExprStep * 1)(E.EcExprStep(eco.ADD, 0, 8, 0))
+    assert L.ec_expr(bad_dt, p, 1, sc, 1, st, 1, N, out.mem.ptr, ec.stream()) == E.EC_ERR_UNSUPPORTED_TYPE
+
+
 SMALL = {  # cell type -> (lowest, highest) cell value
     "UInt8": (0, 255), "Int8": (-128, 127), "UInt16": (0, 65535), "Int16": (-32768, 32767),
 }

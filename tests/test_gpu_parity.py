@@ -611,6 +611,51 @@ def test_streams_threads_and_graph_capture(ec):
         assert (mn.bits(), mx.bits()) == (emn.bits(), emx.bits())
 
 
+def test_fused_chain_over_four_cell_types_in_a_hipgraph(ec):
+    """Rounds 1-2 widened mixed-type operands into pooled temporaries first, so such a call could not be captured.  Every
+    fused call is now one allocation-free launch: `(u8 - i16) / (f32 + f64)` with four masks is captured once and replayed
+    on new contents of the same buffers."""
+    import ctypes as C
+    import torch
+    L = ec.lib()
+    n = (1 << 18) + 5
+    types = (eco.U8, eco.I16, eco.F32, eco.F64)
+    np_t = (np.uint8, np.int16, np.float32, np.float64)
+    side = torch.cuda.Stream()
+    bufs = [torch.empty(n * np.dtype(t).itemsize, dtype=torch.uint8, device="cuda") for t in np_t]
+    masks = [torch.empty(n, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    out, om = torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda")
+    dt4 = (C.c_uint8 * 4)(*types)
+    p4 = (C.c_void_p * 4)(*[b.data_ptr() for b in bufs])
+    m4 = (C.c_void_p * 4)(*[m.data_ptr() for m in masks])
+
+    def fill(seed):
+        host = [rand_cells(t, n, seed + k) for k, t in enumerate(types)]
+        hm = [rand_mask(n, seed + 10 + k) for k in range(4)]
+        for b, h in zip(bufs, host):
+            b.copy_(torch.from_numpy(h.view(np.uint8)))
+        for m, h in zip(masks, hm):
+            m.copy_(torch.from_numpy(h))
+        return host, hm
+
+    host, hm = fill(900)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        h = torch.cuda.current_stream().cuda_stream
+        ec._ffi.check(L.ec_masked_fused(eco.SUB, eco.DIV, eco.ADD, dt4, p4, m4, None, n, out.data_ptr(), om.data_ptr(), h))
+    for trial in range(2):
+        if trial == 1:
+            host, hm = fill(950)
+        g.replay()
+        torch.cuda.synchronize()
+        e1, e2 = eco.f_binop(eco.SUB, host[0], host[1]), eco.f_binop(eco.ADD, host[2], host[3])
+        exp = eco.f_binop(eco.DIV, e1, e2)
+        from vectors import chain_loose
+        assert_f64_bits_equal(out.cpu().numpy(), exp, nan_by_class_where=chain_loose(eco.SUB, host[0], host[1], eco.DIV, e1, e2, eco.ADD, host[2], host[3]))
+        assert np.array_equal(om.cpu().numpy(), hm[0] & hm[1] & hm[2] & hm[3])
+
+
 @pytest.mark.timeout(300)
 def test_native_rccl_allreduce_of_reduction_payloads(ec):
     """ec_allreduce_min_max_keys / ec_allreduce_counts drive RCCL directly (no torch): a 1-rank

@@ -25,6 +25,7 @@ C_BASE = {  # C base type -> Rust spelling
     # the ABI's own names exist on both sides (their definitions are compared separately)
     "ec_status": "ec_status", "ec_dtype": "ec_dtype", "ec_op": "ec_op", "ec_stream": "ec_stream", "ec_comm": "ec_comm",
     "ec_value": "ec_value", "ec_comm_uid": "ec_comm_uid", "ec_shard_group": "ec_shard_group", "ec_shard_fn": "ec_shard_fn",
+    "ec_expr_step": "ec_expr_step",
 }
 
 
@@ -213,3 +214,28 @@ def test_ec_value_layout_is_what_the_c_compiler_says(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     assert [int(x) for x in out] == [16, 0, 1, 8, 128]
     assert re.search(r"pub struct ec_comm_uid\s*\{\s*pub bytes:\s*\[c_char;\s*128\]", rs)
+
+
+def test_ec_expr_step_layout_and_operand_references(tmp_path):
+    """`ec_expr_step` is four `int8_t` in the order op, a, b, dst on both sides (4 bytes, no padding), and the operand
+    reference helpers and limits of ffi.rs give the numbers of the header's macros and enum."""
+    rs = open(FFI_RS).read()
+    m = re.search(r"#\[repr\(C\)\]\s*#\[derive\([^)]*\)\]\s*pub struct ec_expr_step\s*\{([^}]*)\}", rs)
+    assert m, "ffi.rs lacks #[repr(C)] ec_expr_step"
+    fields = re.findall(r"pub (\w+)\s*:\s*(\w+)", m.group(1))
+    assert fields == [("op", "i8"), ("a", "i8"), ("b", "i8"), ("dst", "i8")], fields
+    prog = tmp_path / "step.c"
+    prog.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "erased_cells.h"\n'
+                    'int main(void) { printf("%zu %zu %zu %zu %zu %d %d %d %d %d %d %d\\n", sizeof(ec_expr_step), '
+                    'offsetof(ec_expr_step, op), offsetof(ec_expr_step, a), offsetof(ec_expr_step, b), offsetof(ec_expr_step, dst), '
+                    'EC_EXPR_STREAM(3), EC_EXPR_REG(3), EC_EXPR_SCALAR(7), EC_EXPR_MAX_STREAMS, EC_EXPR_REGS, '
+                    'EC_EXPR_MAX_SCALARS, EC_EXPR_MAX_STEPS); return 0; }\n')
+    exe = tmp_path / "step"
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert out[:5] == [4, 0, 1, 2, 3]
+    base = {k: int(v) for k, v in re.findall(r"pub const fn ec_expr_(stream|reg|scalar)\(k: i8\) -> i8 \{\s*(?:(\d+) \+ )?k\s*\}", rs)
+            for v in [v or "0"]}
+    assert [base["stream"] + 3, base["reg"] + 3, base["scalar"] + 7] == out[5:8]
+    lim = {k: int(v) for k, v in re.findall(r"pub const (EC_EXPR_\w+): usize = (\d+);", rs)}
+    assert [lim["EC_EXPR_MAX_STREAMS"], lim["EC_EXPR_REGS"], lim["EC_EXPR_MAX_SCALARS"], lim["EC_EXPR_MAX_STEPS"]] == out[8:]

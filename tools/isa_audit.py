@@ -32,7 +32,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "erased-cells_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-DEFAULT_TUS = ["ec_abi.hip", "ec_binop_div.hip", "ec_fusedany_c1.hip", "ec_fusedany_c4.hip"]
+DEFAULT_TUS = ["ec_abi.hip", "ec_binop_div.hip", "ec_fusedany_c1.hip", "ec_fusedany_c4.hip", "ec_expr_c1.hip", "ec_expr_c2.hip"]
 SKIP = re.compile(r"cellwise|finalize")
 MEM = re.compile(r"^\s+((?:global|buffer)_(load|store)_\w+)\s+(.*)$")
 KERNEL = re.compile(r"^(_Z\S+):")
