@@ -411,7 +411,7 @@ def main():
         else:
             # the reference's eager evaluation: every operator one pass over f64 temporaries
             t = [ec.CellBuffer.empty(n, ec.Float64) for _ in range(7)]  # one temporary per operator, as the reference allocates
-            bytes_per_cell = (2 + 2 + 8) + (8 + 8) + (2 + 8) + (2 + 8 + 8) + (2 + 8) + (8 + 8 + 8) + (8 + 8) + (8 + 8 + 8)  # 136
+            bytes_per_cell = (2 + 2 + 8) + (8 + 8) + (2 + 8) + (2 + 8 + 8) + (2 + 8) + (8 + 8 + 8) + (8 + 8) + (8 + 8 + 8)  # 130
             kernel = "k_binop_direct / k_binop_scalar x 8 (f64 temporaries): eager, 8 passes"
             U16, F64 = ec.UInt16, ec.Float64
 

@@ -27,12 +27,12 @@ namespace ecd {
 constexpr int kExprMaxStreams = 4, kExprRegs = 4, kExprMaxScalars = 8, kExprMaxSteps = 16;
 // operand references of a step
 constexpr int kRefStream0 = 0, kRefReg0 = 4, kRefScalar0 = 8, kRefEnd = 16;
-// cell PAIRS per lane per tile.  A step is decoded once per wave, so more cells per wave amortise the decode — but the
-// register file costs 16 VGPRs per cell: 2 pairs = 100 VGPRs, 5 waves per SIMD; 4 pairs = 188 VGPRs, 2 waves per SIMD, and
-// measured 6 % SLOWER on EVI (1.139 vs 1.070 ms, profiles/r03/expr_kernel.md): two waves cannot cover each other's
-// scalar-branch latency.
+// cell PAIRS per lane per tile.  A step is decoded once per wave (≈ 45 scalar instructions: the binding cost),
+// so more cells per wave amortise the decode — but the register file costs 16 VGPRs per cell and the waves of a SIMD must
+// still cover each other's scalar-branch latency.  Measured on EVI at 16384² (profiles/r03/expr_kernel.md):
+//   2 pairs (100 VGPRs, 5 waves/SIMD) 1.070 ms;  3 pairs (3 waves/SIMD) 0.992 ms;  4 pairs (188 VGPRs, 2 waves/SIMD) 1.139 ms.
 #ifndef EC_EXPR_U
-#define EC_EXPR_U 2
+#define EC_EXPR_U 3
 #endif
 constexpr int kExprU = EC_EXPR_U;
 

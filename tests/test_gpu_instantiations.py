@@ -476,6 +476,14 @@ def test_expr_random_programs_masks_windows_and_the_eager_chain(ec, pool):
         got = P.program(bufs, scalars, steps)
         eo, loose = _oracle_program(hs, scalars, steps)
         assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+        if trial % 4 == 1:  # k_expr_cellwise: the any-alignment path behind the unaligned_vector knob
+            ec.lib().ec_tune_set(b"unaligned_vector", 0)
+            try:
+                cw = (P.program([ec.MaskedCellBuffer(b, dm[k % 2].shard(off + k, n)) for k, b in enumerate(bufs)], scalars, steps)
+                      if trial % 8 == 1 else P.program(bufs, scalars, steps))
+            finally:
+                ec.lib().ec_tune_set(b"unaligned_vector", 1)
+            assert_f64_bits_equal((cw.buffer() if trial % 8 == 1 else cw).to_numpy(), eo, nan_by_class_where=loose)
         # the eager chain on the device: every step one operator call
         regs = {}
         for op, a, b, dst in steps:

@@ -172,6 +172,20 @@ def main():
     p3 = (C.c_void_p * 4)(a.mem.ptr, b.mem.ptr, f64.mem.ptr, None)
     bench("fused (a+b)*c Float32,Float32,Float64 (one pass, mixed)", 4 + 4 + 8 + 8, lambda: chk(L.ec_fused(ec.ADD, ec.MUL, -1, dt3, p3, None, n, out64.mem.ptr, stream)))
 
+    # ---- expression programs (k_expr): bound by instruction issue, not by HBM, beyond two or three steps
+    E = ec._ffi
+    u16c = synth(ec.UInt16, 19, 1, 30000)
+    dt3e = (C.c_uint8 * 3)(ec.UInt16, ec.UInt16, ec.UInt16)
+    p3e = (C.c_void_p * 3)(u16.mem.ptr, u16b.mem.ptr, u16c.mem.ptr)
+    sce = (E.EcValue * 4)(*[ec.CellValue.new(x).to_ec() for x in (2.5, 6.0, 7.5, 1.0)])
+    S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+    evi = [(ec.SUB, S(0), S(1), 0), (ec.MUL, R(0), K(0), 0), (ec.MUL, S(1), K(1), 1), (ec.ADD, S(0), R(1), 1),
+           (ec.MUL, S(2), K(2), 2), (ec.SUB, R(1), R(2), 1), (ec.ADD, R(1), K(3), 1), (ec.DIV, R(0), R(1), 0)]
+    two = [(ec.ADD, S(0), S(1), 0), (ec.MUL, R(0), S(2), 0)]
+    for label, prog in (("expr (a+b)*c UInt16 x3, 2 steps", two), ("expr EVI UInt16 x3, 8 steps, 4 scalars", evi)):
+        st = (E.EcExprStep * len(prog))(*[E.EcExprStep(*q) for q in prog])
+        bench(label, 2 + 2 + 2 + 8, lambda st=st, k=len(prog): chk(L.ec_expr(dt3e, p3e, 3, sce, 4, st, k, n, out64.mem.ptr, stream)))
+
     print(f"Per-kernel roofline table, {side}x{side} = {n} cells, one MI355X, HIP-event timed over >= 40 ms of launches after an "
           f"equal untimed ramp, peak {PEAK:.0f} GB/s, map_u={map_u}\n")
     print("Same operands every launch.  `frac`: the library's load policy (an operand that fits the 256 MiB Infinity Cache is kept "
