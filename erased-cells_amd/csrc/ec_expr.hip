@@ -85,7 +85,7 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
     }
     // peel one leading cell when that puts more of the 1-byte streams on even addresses (peel_head's rule)
     unsigned c0 = 0, c1 = 0;
-    size_t stream_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0}, narrowest = 8;
+    size_t stream_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int cls[kExprMaxStreams] = {0, 0, 0, 0};
     for (int k = 0; k < n_streams; ++k) {
         const size_t bytes = ecl::size_of(dt[k]);
@@ -93,11 +93,16 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
         c1 += peel_cost(p[k], bytes, 1);
         cls[k] = fused_class_index(bytes);
         stream_bytes[k] = n * bytes;
-        if (bytes < narrowest) narrowest = bytes;
+        for (int j = 0; j < k; ++j)
+            if (p[j] == p[k]) stream_bytes[k] = 0;  // the same buffer again: its bytes count once (policy copied below)
     }
     for (int j = 0; j < ea.nmask; ++j) stream_bytes[4 + j] = n;
     ea.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
-    ea.cacheable = static_cast<uint8_t>(cache_plan(stream_bytes, 8));
+    unsigned policy = cache_plan(stream_bytes, 8);
+    for (int k = 1; k < n_streams; ++k)
+        for (int j = 0; j < k; ++j)
+            if (p[j] == p[k]) policy = (policy & ~(1u << k)) | (((policy >> j) & 1u) << k);  // one buffer, one policy
+    ea.cacheable = static_cast<uint8_t>(policy);
     const size_t per_tile = size_t(kBlock) * kExprU;
     const unsigned grid = grid_for((((n - ea.head) >> 1) + per_tile - 1) / per_tile);
     ExprKernel kern = nullptr;

@@ -531,6 +531,48 @@ def test_lazy_trees_deeper_than_two_levels_run_as_one_pass(ec, pool):
     assert np.array_equal(bits_of(got.to_numpy()), bits_of((((a + b) * c) - ((d / e) + a)).to_numpy()))
 
 
+def test_lazy_random_trees_against_the_oracle(ec, pool):
+    """Random operator trees (depth ≤ 5, leaves from six buffers of different types and scalars on either side) written
+    with `lazy()`: whatever the evaluator does with them — the two-level kernel, one expression program, or a cut into
+    pieces when the tree needs more than four buffers or registers — the cells are the oracle's, evaluated node by node."""
+    host, dev, _, _ = pool
+    L = ec.fused.lazy
+    rng = np.random.default_rng(99)
+    cts = [eco.U16, eco.F32, eco.U8, eco.I32, eco.F64, eco.I16]
+    bufs = [dev[ct].shard(k, N) for k, ct in enumerate(cts)]
+    hs = [host[ct][k:k + N] for k, ct in enumerate(cts)]
+
+    def grow(depth, nbuf):
+        """-> (lazy tree or scalar, oracle value, loose, has_buffer)"""
+        if depth == 0 or rng.random() < 0.25:
+            if rng.random() < 0.3:
+                c = float(rng.choice([2.5, -3.0, 0.5, 7.0, 65536.0, 1.0]))
+                return c, np.full(N, c), np.zeros(N, bool), False
+            k = int(rng.integers(0, nbuf))
+            return L(bufs[k]), hs[k], np.zeros(N, bool), True
+        op = int(rng.integers(0, 4))
+        a, va, la, ba = grow(depth - 1, nbuf)
+        b, vb, lb, bb = grow(depth - 1, nbuf)
+        if not (ba or bb):  # two scalars: keep one side a buffer so that the node is an operator of the library
+            a, va, la, ba = L(bufs[0]), hs[0], np.zeros(N, bool), True
+        t = [a + b, a - b, a * b, a / b][op] if not isinstance(a, float) or not isinstance(b, float) else None
+        lo = la | lb
+        if op in (eco.ADD, eco.MUL):
+            lo = lo | _both_nan(va, vb)
+        return t, eco.f_binop(op, va, vb), lo, True
+
+    seen_programs = 0
+    for trial in range(40):
+        t, exp, loose, _ = grow(int(rng.integers(2, 6)), 3 if trial % 2 else 6)
+        if not isinstance(t, ec.fused.Lazy) or t.op is None:
+            continue
+        before = _pool_allocs(ec)
+        got = t.eval()
+        seen_programs += _pool_allocs(ec) == before + 1 and t._depth() > 2
+        assert_f64_bits_equal(got.to_numpy(), exp, nan_by_class_where=loose)
+    assert seen_programs >= 5, "deep trees over three buffers should have run as single programs"
+
+
 def test_expr_rejects_malformed_programs(ec, pool):
     host, dev, _, _ = pool
     L, E = ec.lib(), ec._ffi
