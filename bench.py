@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--workload", default="div_u8_u16", choices=["div_u8_u16", "masked_chain", "minmax", "ndvi", "binop", "evi"])
     ap.add_argument("--lt", default="u16", help="--workload binop: lhs cell type (u8 u16 u32 u64 i8 i16 i32 i64 f32 f64)")
     ap.add_argument("--rt", default="u16", help="--workload binop: rhs cell type")
+    ap.add_argument("--interpret", action="store_true", help="--workload evi --fused: the interpreter kernel (k_expr) instead of the "
+                    "program compiled for itself with hiprtc (the library's default once a program has run long enough)")
     ap.add_argument("--op", default="add", choices=["add", "sub", "mul", "div"], help="--workload binop: operator")
     ap.add_argument("--fused", action="store_true", help="masked_chain / ndvi: the single-pass fused kernel instead of the eager chain")
     ap.add_argument("--mixed", action="store_true", help="ndvi: red band as f32 (mixed operand types -> the generic fused kernel)")
@@ -396,7 +398,11 @@ def main():
         traffic_key = "evi" + ("_fused" if args.fused else "")
         sc = (E.EcValue * 4)(*[ec.CellValue.new(x).to_ec() for x in (2.5, 6.0, 7.5, 1.0)])
         if args.fused:
-            bytes_per_cell, kernel = 14, "k_expr<2,2,2,0>: 8 operators over 3 u16 bands, one pass"
+            # compiled on the calling thread before the first launch (in a pipeline the library does it in the background)
+            chk(L.ec_tune_set(b"expr_jit", 0 if args.interpret else 2))
+            traffic_key += "" if args.interpret else "_compiled"
+            bytes_per_cell = 14
+            kernel = ("k_expr<2,2,2,0> (interpreter)" if args.interpret else "ec_expr_jit (the program compiled with hiprtc)") + ": 8 operators over 3 u16 bands, one pass"
             S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
             prog = [(ec.SUB, S(0), S(1), 0), (ec.MUL, R(0), K(0), 0),      # r0 = (nir - red) * 2.5
                     (ec.MUL, S(1), K(1), 1), (ec.ADD, S(0), R(1), 1),      # r1 = nir + red * 6
@@ -424,7 +430,7 @@ def main():
                 chk(L.ec_binop(ec.SUB, F64, t[3].mem.ptr, F64, t[4].mem.ptr, n, t[5].mem.ptr, stream))
                 chk(L.ec_binop_scalar(ec.ADD, F64, t[5].mem.ptr, n, C.byref(sc[3]), t[6].mem.ptr, stream))
                 chk(L.ec_binop(ec.DIV, F64, t[1].mem.ptr, F64, t[6].mem.ptr, n, out.mem.ptr, stream))
-        wl = f"{side}x{side} u16 EVI 2.5(nir-red)/(nir+6red-7.5blue+1), 8 operators, " + ("one pass (ec_expr)" if args.fused else "eager")
+        wl = f"{side}x{side} u16 EVI 2.5(nir-red)/(nir+6red-7.5blue+1), 8 operators, " + (("one pass (ec_expr, " + ("interpreted" if args.interpret else "compiled") + ")") if args.fused else "eager")
     else:
         a = ec.CellBuffer.empty(n, ec.UInt16)
         chk(L.ec_synth_fill(ec.UInt16, a.mem.ptr, n, 0x5EED0006, off, 1.0, 65534.0, stream))

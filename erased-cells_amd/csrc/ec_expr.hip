@@ -2,32 +2,38 @@
 // liveness, operand set-up and dispatch by the streams' byte widths.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstring>
+
 #include "ec_expr.hpp"
+#include "ec_expr_jit.hpp"
 #include "ec_lattice.hpp"
 #include "ec_runtime.hpp"
 
 using namespace ecd;
 
-static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n_streams, const uint8_t* const* masks,
-                             const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
-                             double* out, uint8_t* out_mask, hipStream_t s, const char* what) {
+static std::atomic<int64_t> g_interpreted{0};  // launches of the interpreter's vector kernel (ec_stat_get("expr_interp_launches"))
+
+namespace ecd {
+int64_t expr_stat(const char* key, bool* known) {
+    if (!std::strcmp(key, "expr_interp_launches")) {
+        *known = true;
+        return g_interpreted.load(std::memory_order_relaxed);
+    }
+    return expr_jit_stat(key, known);
+}
+}  // namespace ecd
+
+// The program part of a call, checked and packed: counts, cell types, steps (with the host's marks), no pointers.
+static ec_status program_of(ExprArgs& ea, const ec_dtype* dt, int32_t n_streams, int32_t n_scalars, const ec_expr_step* steps,
+                            int32_t n_steps, const char* what) {
     if (n_streams < 1 || n_streams > kExprMaxStreams) return set_error(EC_ERR_ARG, "%s: %d operand streams (1..%d)", what, int(n_streams), kExprMaxStreams);
     if (n_scalars < 0 || n_scalars > kExprMaxScalars) return set_error(EC_ERR_ARG, "%s: %d scalars (0..%d)", what, int(n_scalars), kExprMaxScalars);
     if (n_steps < 1 || n_steps > kExprMaxSteps) return set_error(EC_ERR_ARG, "%s: %d steps (1..%d)", what, int(n_steps), kExprMaxSteps);
-    if (!dt || !p || !steps || !out || (n_scalars > 0 && !scalars)) return set_error(EC_ERR_ARG, "%s: null pointer", what);
-    ExprArgs ea{};
-    bool aligned = aligned_to(out, 16);
+    if (!dt || !steps) return set_error(EC_ERR_ARG, "%s: null pointer", what);
     for (int k = 0; k < n_streams; ++k) {
         if (!ecl::valid(dt[k])) return set_error(EC_ERR_UNSUPPORTED_TYPE, "%s: bad dtype of stream %d", what, k);
-        if (!p[k]) return set_error(EC_ERR_ARG, "%s: stream %d is null", what, k);
-        ea.p[k] = p[k];
         ea.dt[k] = static_cast<int8_t>(dt[k]);
-        aligned = aligned && aligned_to(p[k], 16);
-    }
-    for (int k = n_streams; k < kExprMaxStreams; ++k) ea.p[k] = p[0];  // never read (class 0)
-    for (int k = 0; k < n_scalars; ++k) {
-        if (!ecl::valid(scalars[k].dtype)) return set_error(EC_ERR_ARG, "%s: bad dtype of scalar %d", what, k);
-        ea.sc[k] = ec_value_to_f64(&scalars[k]);  // impl $trt<R: Into<CellValue>> (src/buffer.rs:346-352): widened once, here
     }
     bool written[kExprRegs] = {false, false, false, false};
     for (int k = 0; k < n_steps; ++k) {
@@ -66,6 +72,27 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
     }
     ea.nstreams = static_cast<int8_t>(n_streams);
     ea.nsteps = static_cast<int8_t>(n_steps);
+    return EC_OK;
+}
+
+static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n_streams, const uint8_t* const* masks,
+                             const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
+                             double* out, uint8_t* out_mask, hipStream_t s, const char* what) {
+    ExprArgs ea{};
+    ec_status pst = program_of(ea, dt, n_streams, n_scalars, steps, n_steps, what);
+    if (pst != EC_OK) return pst;
+    if (!p || !out || (n_scalars > 0 && !scalars)) return set_error(EC_ERR_ARG, "%s: null pointer", what);
+    bool aligned = aligned_to(out, 16);
+    for (int k = 0; k < n_streams; ++k) {
+        if (!p[k]) return set_error(EC_ERR_ARG, "%s: stream %d is null", what, k);
+        ea.p[k] = p[k];
+        aligned = aligned && aligned_to(p[k], 16);
+    }
+    for (int k = n_streams; k < kExprMaxStreams; ++k) ea.p[k] = p[0];  // never read (class 0)
+    for (int k = 0; k < n_scalars; ++k) {
+        if (!ecl::valid(scalars[k].dtype)) return set_error(EC_ERR_ARG, "%s: bad dtype of scalar %d", what, k);
+        ea.sc[k] = ec_value_to_f64(&scalars[k]);  // impl $trt<R: Into<CellValue>> (src/buffer.rs:346-352): widened once, here
+    }
     if (masks) {
         if (!out_mask) return set_error(EC_ERR_ARG, "%s: null out_mask", what);
         aligned = aligned && aligned_to(out_mask, 16);
@@ -103,6 +130,19 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
         for (int j = 0; j < k; ++j)
             if (p[j] == p[k]) policy = (policy & ~(1u << k)) | (((policy >> j) & 1u) << k);  // one buffer, one policy
     ea.cacheable = static_cast<uint8_t>(policy);
+    // The program compiled for itself (ec_expr_jit.hpp), once it is ready: the value phase as straight-line code; the masks'
+    // AND is then its own small launch.  Until then — and whenever expr_jit is 0 — the interpreter below.
+    bool compiled = false;
+    ec_status jst = expr_jit_launch(ea, n, out, s, &compiled);
+    if (jst != EC_OK) return jst;
+    if (compiled) {
+        if (ea.nmask > 0) {
+            const size_t groups = (n + 15) / 16;
+            k_expr_masks<0><<<grid_capped((groups + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(ea, out_mask, n);
+        }
+        return check_launch("expr(compiled)");
+    }
+    g_interpreted.fetch_add(1, std::memory_order_relaxed);
     const size_t per_tile = size_t(kBlock) * kExprU;
     const unsigned grid = grid_for((((n - ea.head) >> 1) + per_tile - 1) / per_tile);
     ExprKernel kern = nullptr;
@@ -133,4 +173,25 @@ extern "C" ec_status ec_masked_expr(const ec_dtype* dt, const void* const* p, co
     if (n == 0) return EC_OK;
     if (!masks) return set_error(EC_ERR_ARG, "ec_masked_expr: null masks");
     return launch_expr(dt, p, n_streams, masks, scalars, n_scalars, steps, n_steps, n, out, out_mask, static_cast<hipStream_t>(stream), "ec_masked_expr");
+}
+
+// Diagnostics, no device needed: the source the library would compile for this program (all streams non-temporal), and a
+// trial compile of it when `arch_or_null` names a processor.
+extern "C" ec_status ec_expr_source(const ec_dtype* dt, int32_t n_streams, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps,
+                                    const char* arch_or_null, char* buf, size_t cap, size_t* len) {
+    ExprArgs ea{};
+    ec_status st = program_of(ea, dt, n_streams, n_scalars, steps, n_steps, "ec_expr_source");
+    if (st != EC_OK) return st;
+    const std::string src = expr_jit_source(ea);
+    if (len) *len = src.size() + 1;
+    if (buf && cap > 0) {
+        const size_t k = src.size() < cap - 1 ? src.size() : cap - 1;
+        std::memcpy(buf, src.data(), k);
+        buf[k] = 0;
+    }
+    if (arch_or_null) {
+        std::string code, log;
+        return expr_jit_compile(src, arch_or_null, &code, &log);
+    }
+    return EC_OK;
 }

@@ -115,6 +115,8 @@ static thread_local uint64_t t_generation = 0;
 static thread_local int t_active = -1;          // device bound by the last ensure_ready()
 static thread_local int t_cus = 256;
 
+int64_t expr_stat(const char* key, bool* known);  // ec_expr.hip
+void expr_jit_release();                             // ec_expr_jit.hip
 Tuning& tuning() { return g_tuning; }
 int device_cus() { return t_cus; }
 int current_device() { return t_active; }
@@ -265,6 +267,7 @@ extern "C" ec_status ec_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     int before = -1;
     const bool had = !g_devs.empty() && hipGetDevice(&before) == hipSuccess;
+    if (!g_devs.empty()) expr_jit_release();  // modules of run-time compiled expression programs (ec_expr_jit.hip)
     for (auto& kv : g_devs) {
         if (hipSetDevice(kv.first) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
@@ -461,7 +464,11 @@ extern "C" ec_status ec_stat_get(const char* key, int64_t* value) {
         int64_t n = 0;
         for (auto& kv : g_devs) n += static_cast<int64_t>(kv.second.scratch.size());
         *value = n;
-    } else return set_error(EC_ERR_ARG, "ec_stat_get: unknown key '%s'", key);
+    } else {
+        bool known = false;
+        *value = expr_stat(key, &known);  // expr_interp_launches, expr_jit_launches / _compiles / _failures / _programs
+        if (!known) return set_error(EC_ERR_ARG, "ec_stat_get: unknown key '%s'", key);
+    }
     return EC_OK;
 }
 
@@ -477,6 +484,7 @@ extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     else if (!std::strcmp(key, "fused_mixed")) g_tuning.fused_mixed = static_cast<int>(value);
     else if (!std::strcmp(key, "mall_mb")) g_tuning.mall_mb = value < 0 ? 0 : value;
     else if (!std::strcmp(key, "inject_shard_failure")) g_tuning.inject_shard_failure = static_cast<int>(value);
+    else if (!std::strcmp(key, "expr_jit")) g_tuning.expr_jit = value < 0 ? 0 : value > 2 ? 2 : static_cast<int>(value);
     else if (!std::strcmp(key, "pool_keep_mb")) {
         g_tuning.pool_keep_mb = value < 0 ? 0 : value;
         std::lock_guard<std::mutex> lk(g_mu);

@@ -46,6 +46,8 @@ struct Tuning {
                                            // the default cache policy, all others non-temporal; 0 = every stream non-temporal
     std::atomic<int> inject_shard_failure{0};  // test hook: shard index + 1 whose NEXT fire-and-forget job of a shard group reports
                                                // EC_ERR_HIP instead of launching (exercises the deferred-error path); 0 = off
+    std::atomic<int> expr_jit{1};  // expression programs compiled at run time (ec_expr_jit.hpp): 0 never, 1 in the background once a
+                                   // program has interpreted 2^31 cell-steps, 2 on the calling thread at first sight
     std::atomic<int64_t> pool_keep_mb{32768};  // release threshold of the library's stream-ordered pool (per device)
 };
 

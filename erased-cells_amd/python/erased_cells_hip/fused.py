@@ -94,6 +94,19 @@ def program(streams, scalars, steps):
     return B.MaskedCellBuffer(out, om)
 
 
+def program_source(cell_types, n_scalars, steps, arch=None) -> str:
+    """The HIP source the library compiles for a program when it compiles it for itself (`ec_expr_source`; no GPU needed).
+    With `arch` (e.g. "gfx950") the source is also compiled once with hiprtc; a failure raises with the compiler's log."""
+    from ._ffi import EcExprStep
+    dt = (C.c_uint8 * len(cell_types))(*cell_types)
+    st = (EcExprStep * len(steps))(*[EcExprStep(*s_) for s_ in steps])
+    need = C.c_size_t(0)
+    check(lib().ec_expr_source(dt, len(cell_types), n_scalars, st, len(steps), None, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    check(lib().ec_expr_source(dt, len(cell_types), n_scalars, st, len(steps), arch.encode() if arch else None, buf, need.value, C.byref(need)))
+    return buf.value.decode()
+
+
 class _Compiler:
     """Schedules an operator tree onto the four registers of `ec_expr`: post-order, the sub-tree that needs more
     registers first (Sethi-Ullman), a register freed as soon as its value has been consumed.  `compile` returns None when

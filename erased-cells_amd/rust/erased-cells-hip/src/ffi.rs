@@ -143,6 +143,8 @@ extern "C" {
     pub fn ec_masked_expr(dt: *const ec_dtype, p: *const *const c_void, masks: *const *const u8, n_streams: i32,
                           scalars: *const ec_value, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32, n: usize,
                           out: *mut f64, out_mask: *mut u8, s: ec_stream) -> ec_status;
+    pub fn ec_expr_source(dt: *const ec_dtype, n_streams: i32, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32,
+                          arch_or_null: *const c_char, buf: *mut c_char, cap: usize, len: *mut usize) -> ec_status;
     pub fn ec_comm_get_unique_id(uid: *mut ec_comm_uid) -> ec_status;
     pub fn ec_comm_init_rank(uid: *const ec_comm_uid, n_ranks: i32, rank: i32, comm: *mut ec_comm) -> ec_status;
     pub fn ec_comm_init_all(devices: *const i32, n: i32, comms: *mut ec_comm) -> ec_status;

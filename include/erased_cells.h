@@ -222,6 +222,21 @@ ec_status ec_expr(const ec_dtype *dt, const void *const *p, int32_t n_streams, c
 ec_status ec_masked_expr(const ec_dtype *dt, const void *const *p, const uint8_t *const *masks, int32_t n_streams,
                          const ec_value *scalars, int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps,
                          size_t n, double *out, uint8_t *out_mask, ec_stream stream);
+/* How ec_expr runs a program.  The kernel that serves every program is an interpreter (a step is decoded once per wave):
+ * bound by instruction issue, ≈ 0.04 ms per step over 16384^2 cells beyond the first.  A program is launch-uniform, so
+ * the library can also compile it for itself — straight-line code with typed loads, through hiprtc (resolved lazily;
+ * without it the interpreter keeps serving) — and cache the module per (program, cell types, load policy).  Same cells
+ * either way.  ec_tune_set("expr_jit", v): 0 = never compile; 1 (default) = compile on a background thread once a
+ * program has interpreted 2^31 cell-steps, launches interpret until the module is ready; 2 = compile on the calling
+ * thread at first sight (≈ 0.3 s per program, 3 s for the first) and fail loudly if that fails.  Inside a stream
+ * capture a program whose module is not loaded yet is interpreted.  ec_stat_get: "expr_interp_launches",
+ * "expr_jit_launches", "expr_jit_compiles", "expr_jit_failures", "expr_jit_programs".
+ *
+ * ec_expr_source (diagnostics; needs no device): the HIP source the library would compile for the program (every stream
+ * non-temporal) into buf[0..cap), *len = bytes needed with the terminating 0; with `arch_or_null` (e.g. "gfx950") also
+ * a trial compile, EC_ERR_HIP and the compiler's log in ec_last_error() if it fails. */
+ec_status ec_expr_source(const ec_dtype *dt, int32_t n_streams, int32_t n_scalars, const ec_expr_step *steps,
+                         int32_t n_steps, const char *arch_or_null, char *buf, size_t cap, size_t *len);
 
 /* ---------------------------------------------------------------- *
  * min/max under the reference's total order (ints natural; floats total_cmp),

@@ -1,0 +1,77 @@
+"""The run-time compiled form of an expression program, as far as it goes without a GPU: `ec_expr_source` validates a
+program, writes the HIP source the library would compile for it and — given a processor name — compiles it once with
+hiprtc (which cross-compiles gfx950 here).  The cells the compiled kernels produce are checked on the GPU
+(tests/test_gpu_instantiations.py::test_expr_compiled_form_equals_the_interpreter_and_the_oracle)."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "erased-cells_amd", "python"))
+import erased_cells_hip as ec  # noqa: E402
+
+S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+EVI = [(ec.SUB, S(0), S(1), 0), (ec.MUL, R(0), K(0), 0), (ec.MUL, S(1), K(1), 1), (ec.ADD, S(0), R(1), 1),
+       (ec.MUL, S(2), K(2), 2), (ec.SUB, R(1), R(2), 1), (ec.ADD, R(1), K(3), 1), (ec.DIV, R(0), R(1), 0)]
+HAVE_HIPRTC = any(os.path.exists(os.path.join(d, "libhiprtc.so")) for d in ("/opt/rocm/lib", "/opt/rocm/lib64"))
+
+
+def test_source_is_the_program_written_out():
+    src = ec.fused.program_source([ec.UInt16, ec.Int8, ec.Float64], 4, EVI)
+    assert 'extern "C" __global__ __launch_bounds__(256) void ec_expr_jit(' in src
+    # the steps, in the program's order, on the operands the program names
+    body = src[src.index("static __device__ __forceinline__ void run("):]
+    want = ["t[i] = s0[i] - s1[i];", "t[i] = r0[i] * c0;", "t[i] = s1[i] * c1;", "t[i] = s0[i] + r1[i];", "t[i] = s2[i] * c2;",
+            "t[i] = r1[i] - r2[i];", "t[i] = r1[i] + c3;", "t[i] = r0[i] / r1[i];"]
+    at = 0
+    for line in want:
+        at = body.index(line, at) + 1
+    assert body.count("NANFIX(") == len(EVI)  # every step keeps cv_bin_op!'s NaN rule
+    # typed loads: a pair of u16 cells is one 32-bit word, a pair of i8 cells one 16-bit word taken apart with shifts, f64 as is
+    assert "(const W2*)b + pr" in src and "(int)(w << 24) >> 24" in src and "__builtin_bit_cast(double, x)" in src
+    assert src.count("__builtin_nontemporal_load((const W") == 3, "every stream of the diagnostic source is non-temporal"
+    # head offsets in bytes of each stream's cell type
+    assert "p0 + (unsigned long)head * 2;" in src and "p1 + (unsigned long)head * 1;" in src and "p2 + (unsigned long)head * 8;" in src
+
+
+def test_malformed_programs_are_refused_without_a_device():
+    E, L = ec._ffi, ec.lib()
+    dt = (C.c_uint8 * 1)(ec.UInt16)
+    need = C.c_size_t(0)
+
+    def run(steps, n_streams=1, n_scalars=1, dtv=dt):
+        st = (E.EcExprStep * max(1, len(steps)))(*[E.EcExprStep(*q) for q in steps])
+        return L.ec_expr_source(dtv, n_streams, n_scalars, st, len(steps), None, None, 0, C.byref(need))
+
+    assert run([(ec.ADD, 0, 8, 0)]) == E.EC_OK and need.value > 1000
+    assert run([(ec.ADD, 0, 4, 0)]) == E.EC_ERR_ARG       # register read before it is written
+    assert run([(ec.ADD, 1, 8, 0)]) == E.EC_ERR_ARG       # no stream 1
+    assert run([(ec.ADD, 0, 9, 0)]) == E.EC_ERR_ARG       # no scalar 1
+    assert run([(ec.ADD, 0, 8, 4)]) == E.EC_ERR_ARG       # no register 4
+    assert run([(5, 0, 8, 0)]) == E.EC_ERR_ARG
+    assert run([]) == E.EC_ERR_ARG
+    assert run([(ec.ADD, 0, 8, 0)] * 17) == E.EC_ERR_ARG
+    assert run([(ec.ADD, 0, 8, 0)], dtv=(C.c_uint8 * 1)(11)) == E.EC_ERR_UNSUPPORTED_TYPE
+    # a short buffer gets a truncated, terminated copy and the needed length
+    buf = C.create_string_buffer(64)
+    st = (E.EcExprStep * 1)(E.EcExprStep(ec.ADD, 0, 8, 0))
+    assert L.ec_expr_source(dt, 1, 1, st, 1, None, buf, 64, C.byref(need)) == E.EC_OK
+    assert len(buf.value) == 63 and need.value > 64
+
+
+@pytest.mark.skipif(not HAVE_HIPRTC, reason="libhiprtc is not installed here")
+@pytest.mark.timeout(300)
+def test_generated_sources_compile_for_gfx950():
+    """hiprtc accepts what the generator writes: EVI over three cell types, every cell type's loader, a 16-step program with
+    all four ops and every operand kind on either side."""
+    ec.fused.program_source([ec.UInt16, ec.Int8, ec.Float64], 4, EVI, arch="gfx950")
+    ec.fused.program_source([ec.UInt8, ec.UInt32, ec.UInt64, ec.Int16], 1, [(ec.ADD, S(0), S(1), 0), (ec.DIV, S(2), S(3), 1), (ec.MUL, R(0), R(1), 2),
+                                                                          (ec.SUB, K(0), R(2), 3)], arch="gfx950")
+    ec.fused.program_source([ec.Int32, ec.Int64, ec.Float32], 0, [(ec.SUB, S(0), S(1), 0), (ec.DIV, R(0), S(2), 0)], arch="gfx950")
+    long = [(k % 4, [S(0), R(0), K(k % 8)][k % 3] if k else S(0), [K((k + 3) % 8), S(0), R(0)][k % 3] if k else K(0), 0 if k % 5 else (1 if k else 0)) for k in range(16)]
+    long = [(op, a if (a != R(0) or k > 0) else S(0), b if (b != R(0) or k > 0) else S(0), d) for k, (op, a, b, d) in enumerate(long)]
+    ec.fused.program_source([ec.Float64], 8, long, arch="gfx950")
+    with pytest.raises(Exception, match="targets gfx950"):
+        ec.fused.program_source([ec.UInt16], 1, [(ec.ADD, S(0), K(0), 0)], arch="gfx000-no-such-processor")

@@ -573,6 +573,133 @@ def test_lazy_random_trees_against_the_oracle(ec, pool):
     assert seen_programs >= 5, "deep trees over three buffers should have run as single programs"
 
 
+def _stat(ec, key):
+    v = C.c_int64(0)
+    assert ec.lib().ec_stat_get(key, C.byref(v)) == 0
+    return v.value
+
+
+def test_expr_compiled_form_equals_the_interpreter_and_the_oracle(ec, pool):
+    """The run-time compiled form of a program (`expr_jit` = 2: hiprtc on the calling thread): every cell type as a stream,
+    random programs, odd windows (peeled head, odd tail), masks — bit-identical to the interpreter (`expr_jit` = 0) and to
+    the oracle evaluated step by step; the counters say which path ran; a program first met inside a stream capture is
+    interpreted there."""
+    host, dev, m, dm = pool
+    P, L = ec.fused, ec.lib()
+    rng = np.random.default_rng(777)
+
+    def both(bufs, scalars, steps):
+        L.ec_tune_set(b"expr_jit", 2)
+        try:
+            j0, i0 = _stat(ec, b"expr_jit_launches"), _stat(ec, b"expr_interp_launches")
+            jit = P.program(bufs, scalars, steps)
+            assert _stat(ec, b"expr_jit_launches") == j0 + 1 and _stat(ec, b"expr_interp_launches") == i0
+            L.ec_tune_set(b"expr_jit", 0)
+            interp = P.program(bufs, scalars, steps)
+            assert _stat(ec, b"expr_interp_launches") == i0 + 1
+        finally:
+            L.ec_tune_set(b"expr_jit", 1)
+        return jit, interp
+
+    # every cell type as stream 0 (typed loads of the generated kernel), with a second stream of another width
+    for ct in range(NT):
+        other = [eco.F32, eco.U8, eco.I64, eco.U16][ct % 4]
+        for n, off in ((N, 0), (2049, 3), (1, 0), (2, 1)):
+            bufs = [dev[ct].shard(off, n), dev[other].shard(off + 1, n)]
+            hs = [host[ct][off:off + n], host[other][off + 1:off + 1 + n]]
+            steps = [(OPS[ct % 4], P.STREAM0, P.STREAM0 + 1, 0), (eco.MUL, P.REG0, P.SCALAR0, 1), (OPS[(ct + 1) % 4], P.STREAM0 + 1, P.REG0 + 1, 0),
+                     (eco.DIV, P.REG0, P.STREAM0, 2)]
+            jit, interp = both(bufs, [2.5], steps)
+            eo, loose = _oracle_program(hs, [2.5], steps)
+            assert np.array_equal(bits_of(jit.to_numpy()), bits_of(interp.to_numpy())), (ct, n, off)
+            assert_f64_bits_equal(jit.to_numpy(), eo, nan_by_class_where=loose)
+    compiles = _stat(ec, b"expr_jit_compiles")
+    assert compiles >= NT and _stat(ec, b"expr_jit_failures") == 0
+    # random programs, masked every third
+    for trial in range(24):
+        ns = int(rng.integers(1, 5))
+        n, off = [(N, 0), (515, 1), (2049, 3)][trial % 3]
+        cts = [int(c) for c in rng.integers(0, NT, size=ns)]
+        bufs = [dev[ct].shard(off + k, n) for k, ct in enumerate(cts)]
+        hs = [host[ct][off + k:off + k + n] for k, ct in enumerate(cts)]
+        scalars = [float(x) for x in rng.choice([2.5, -3.0, 0.5, 7.0, 1e-3, -0.0], size=int(rng.integers(1, 9)))]
+        written, steps = [], []
+        for _ in range(int(rng.integers(1, 17))):
+            def ref():
+                kind = ["s", "c"] + (["r"] if written else [])
+                kind = kind[int(rng.integers(0, len(kind)))]
+                return (P.STREAM0 + int(rng.integers(0, ns)) if kind == "s" else P.SCALAR0 + int(rng.integers(0, len(scalars))) if kind == "c"
+                        else P.REG0 + int(rng.choice(written)))
+            dst = int(rng.integers(0, 4))
+            steps.append((int(rng.integers(0, 4)), ref(), ref(), dst))
+            if dst not in written:
+                written.append(dst)
+        if trial % 3 == 0:
+            bufs = [ec.MaskedCellBuffer(b, dm[k % 2].shard(off + k, n)) for k, b in enumerate(bufs)]
+        jit, interp = both(bufs, scalars, steps)
+        eo, loose = _oracle_program(hs, scalars, steps)
+        jv, iv = (jit.buffer(), interp.buffer()) if trial % 3 == 0 else (jit, interp)
+        assert np.array_equal(bits_of(jv.to_numpy()), bits_of(iv.to_numpy())), (trial, cts, steps)
+        assert_f64_bits_equal(jv.to_numpy(), eo, nan_by_class_where=loose)
+        if trial % 3 == 0:
+            assert np.array_equal(jit.mask().to_numpy(), interp.mask().to_numpy())
+    # the same program again: served from the cache, nothing compiled
+    before = _stat(ec, b"expr_jit_compiles")
+    both(bufs, scalars, steps)
+    assert _stat(ec, b"expr_jit_compiles") == before
+    # a program first met inside a stream capture: no compile-and-load there — interpreted, and correct on replay
+    import torch
+    x = dev[eco.U16].shard(0, N)
+    out = ec.CellBuffer.empty(N, ec.Float64)
+    E = ec._ffi
+    dt, p = (C.c_uint8 * 1)(eco.U16), (C.c_void_p * 1)(x.mem.ptr)
+    sc = (E.EcValue * 1)(ec.CellValue.new(123.25).to_ec())
+    st = (E.EcExprStep * 2)(E.EcExprStep(eco.MUL, 0, 8, 3), E.EcExprStep(eco.SUB, 7, 0, 1))
+    cap = torch.cuda.Stream()
+    L.ec_tune_set(b"expr_jit", 2)
+    try:
+        chk = E.check
+        chk(L.ec_prepare_stream(cap.cuda_stream))
+        i0 = _stat(ec, b"expr_interp_launches")
+        g = torch.cuda.CUDAGraph()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=cap):
+            chk(L.ec_expr(dt, p, 1, sc, 1, st, 2, N, out.mem.ptr, cap.cuda_stream))
+        g.replay()
+        torch.cuda.synchronize()
+        assert _stat(ec, b"expr_interp_launches") == i0 + 1, "a program first met inside a capture must be interpreted"
+    finally:
+        L.ec_tune_set(b"expr_jit", 1)
+    h = host[eco.U16][:N]
+    exp = eco.f_binop(eco.SUB, eco.f_binop(eco.MUL, h, np.full(N, 123.25)), h)
+    assert_f64_bits_equal(out.to_numpy(), exp)
+
+
+def test_expr_background_compile_takes_over_once_a_program_has_run_long_enough(ec):
+    """`expr_jit` = 1 (the default): launches interpret until a program has interpreted 2^31 cell-steps, a background thread
+    compiles it, and later launches run the compiled form — same cells before and after."""
+    import time
+    P, L, E = ec.fused, ec.lib(), ec._ffi
+    n = 1 << 24
+    x = ec.CellBuffer.empty(n, ec.UInt16)
+    E.check(L.ec_synth_fill(ec.UInt16, x.mem.ptr, n, 0xABCDEF, 0, 1.0, 60000.0, ec.stream()))
+    steps = [(eco.MUL, P.STREAM0, P.SCALAR0, 0)] + [(OPS[k % 3], P.REG0, P.SCALAR0 + (k % 2), 0) for k in range(15)]  # 16 steps
+    scalars = [1.0009765625, 3.0]
+    c0, f0 = _stat(ec, b"expr_jit_compiles"), _stat(ec, b"expr_jit_failures")
+    first = P.program([x], scalars, steps).to_numpy()
+    j0 = _stat(ec, b"expr_jit_launches")
+    for _ in range(8):  # 9 launches x 2^24 cells x 16 steps > 2^31
+        P.program([x], scalars, steps)
+    assert _stat(ec, b"expr_jit_launches") == j0, "nothing is compiled yet: the launches so far were interpreted"
+    deadline = time.time() + 60
+    while _stat(ec, b"expr_jit_compiles") == c0 and _stat(ec, b"expr_jit_failures") == f0 and time.time() < deadline:
+        time.sleep(0.05)
+    assert _stat(ec, b"expr_jit_failures") == f0 and _stat(ec, b"expr_jit_compiles") == c0 + 1
+    later = P.program([x], scalars, steps)
+    assert _stat(ec, b"expr_jit_launches") == j0 + 1
+    assert np.array_equal(bits_of(later.to_numpy()), bits_of(first))
+
+
 def test_expr_rejects_malformed_programs(ec, pool):
     host, dev, _, _ = pool
     L, E = ec.lib(), ec._ffi

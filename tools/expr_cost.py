@@ -16,6 +16,9 @@ S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
 
 
 def main():
+    jit = "--jit" in sys.argv  # every program compiled for itself (hiprtc) instead of interpreted
+    if jit:
+        sys.argv.remove("--jit")
     only = None
     if "--only" in sys.argv:  # one program, few launches: for counter passes under rocprofv3
         k = sys.argv.index("--only")
@@ -27,6 +30,7 @@ def main():
     L, E, C = ec.lib(), ec._ffi, __import__("ctypes")
     stream = torch.cuda.current_stream().cuda_stream
     ec.set_stream(stream)
+    E.check(L.ec_tune_set(b"expr_jit", 2 if jit else 0))
     bands = [ec.CellBuffer.empty(n, ec.UInt16) for _ in range(3)]
     for i, b in enumerate(bands):
         E.check(L.ec_synth_fill(ec.UInt16, b.mem.ptr, n, 0x5EED0031 + i, 0, 2000.0, 30000.0, stream))
@@ -65,6 +69,7 @@ def main():
         "EVI (8 steps: 3 *scalar, 1 +scalar, 1 /)": [(SUB, S(0), S(1), 0), (MUL, R(0), K(0), 0), (MUL, S(1), K(1), 1), (ADD, S(0), R(1), 1),
                                                        (MUL, S(2), K(2), 2), (SUB, R(1), R(2), 1), (ADD, R(1), K(3), 1), (DIV, R(0), R(1), 0)],
     }
+    print(("compiled (hiprtc)" if jit else "interpreter (k_expr)") + "\n")
     print(f"| program over 3 u16 streams, {side}x{side} | ms / launch | Gcells/s | fraction of 8 TB/s at 14 B/cell |")
     print("|---|---|---|---|")
     for name, prog in progs.items():

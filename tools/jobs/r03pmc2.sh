@@ -10,14 +10,16 @@ run() {  # name, counters, bench flags
   find $O/$name -name '*kernel_trace.csv' -delete
   echo "done $name"
 }
-for wl in "evi_fused --workload evi --fused" "evi --workload evi"; do
+for wl in "evi_fused --workload evi --fused --interpret" "evi_fused_compiled --workload evi --fused" "evi --workload evi"; do
   set -- $wl; key=$1; shift
   run ${key}__fetch FETCH_SIZE "$@"
   run ${key}__write WRITE_SIZE "$@"
 done
-run evi_fused__insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES" --workload evi --fused
-run evi_fused__active "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" --workload evi --fused
-run evi_fused__wait "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" --workload evi --fused
+run evi_fused__insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES" --workload evi --fused --interpret
+run evi_fused__active "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" --workload evi --fused --interpret
+run evi_fused__wait "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" --workload evi --fused --interpret
+run evi_fused_compiled__insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES" --workload evi --fused
+run evi_fused_compiled__active "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" --workload evi --fused
 run ndvi_fused__insts "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES" --workload ndvi --fused
 run ndvi_fused__active "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" --workload ndvi --fused
 cd $R
@@ -29,7 +31,7 @@ for d in sorted(glob.glob("gpurun_out/r03pmc2/*__insts") + glob.glob("gpurun_out
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_expr" in r["Kernel_Name"] or "k_fused_any" in r["Kernel_Name"]:
+            if "k_expr" in r["Kernel_Name"] or "k_fused_any" in r["Kernel_Name"] or "ec_expr_jit" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     for k, v in acc.items():
         vals = list(v.values())

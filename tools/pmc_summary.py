@@ -32,6 +32,7 @@ WORKLOADS = {
     "binop_add_u16_u16": (12, 4, ["k_binop_direct"]),
     "binop_add_f32_f32": (16, 8, ["k_binop_direct"]),
     "evi_fused": (14, 6, ["k_expr"]),
+    "evi_fused_compiled": (14, 6, ["ec_expr_jit"]),
     "evi": (130, 66, ["k_binop_direct", "k_binop_scalar"]),
 }
 TRAFFIC_KEY = {"div": "binop_div_u8_u16"}
