@@ -70,13 +70,14 @@ def main():
                                                        (MUL, S(2), K(2), 2), (SUB, R(1), R(2), 1), (ADD, R(1), K(3), 1), (DIV, R(0), R(1), 0)],
     }
     print(("compiled (hiprtc)" if jit else "interpreter (k_expr)") + "\n")
-    print(f"| program over 3 u16 streams, {side}x{side} | ms / launch | Gcells/s | fraction of 8 TB/s at 14 B/cell |")
-    print("|---|---|---|---|")
+    print(f"| program over u16 streams, {side}x{side} | B/cell (streams it reads + f64 out) | ms / launch | Gcells/s | fraction of 8 TB/s |")
+    print("|---|---|---|---|---|")
     for name, prog in progs.items():
         if only and not name.startswith(only):
             continue
         ms = run(prog, reps=5 if only else 60)
-        print(f"| {name} | {ms:.3f} | {n / ms / 1e6:.1f} | {14 * n / ms / 1e6 / 8000:.3f} |")
+        bpc = 8 + 2 * len({r for q in prog for r in q[1:3] if r < 4})
+        print(f"| {name} | {bpc} | {ms:.3f} | {n / ms / 1e6:.1f} | {bpc * n / ms / 1e6 / 8000:.3f} |")
 
 
 if __name__ == "__main__":
