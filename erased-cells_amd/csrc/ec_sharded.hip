@@ -551,6 +551,69 @@ extern "C" ec_status ec_sharded_fused(ec_shard_group* g, ec_op o1, ec_op o2, ec_
     });
 }
 
+// Expression programs (ec_expr / ec_masked_expr) on every shard.  p[k] / masks_or_null[k]: stream k's per-shard pointers.
+// Everything that can be refused is refused here, on the calling thread, the program included.
+extern "C" ec_status ec_sharded_expr(ec_shard_group* g, const ec_dtype* dt, const void* const* const* p,
+                                     const uint8_t* const* const* masks_or_null, int32_t n_streams, const ec_value* scalars,
+                                     int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, const size_t* n, double* const* out,
+                                     uint8_t* const* out_mask_or_null) {
+    ec_status st = check_group(g, "ec_sharded_expr");
+    if (st != EC_OK) return st;
+    if (!dt || !p || !steps || !n || !out || (n_scalars > 0 && !scalars)) return set_error(EC_ERR_ARG, "ec_sharded_expr: null argument");
+    if (n_streams < 1 || n_streams > 4 || n_scalars < 0 || n_scalars > 8 || n_steps < 1 || n_steps > 16)
+        return set_error(EC_ERR_ARG, "ec_sharded_expr: %d streams (1..4), %d scalars (0..8), %d steps (1..16)", int(n_streams), int(n_scalars), int(n_steps));
+    if ((masks_or_null != nullptr) != (out_mask_or_null != nullptr)) return set_error(EC_ERR_ARG, "ec_sharded_expr: masks and out_mask go together");
+    {   // the program: parsed once here (no device needed), so that a malformed one is refused before anything is posted
+        size_t len = 0;
+        if ((st = ec_expr_source(dt, n_streams, n_scalars, steps, n_steps, nullptr, nullptr, 0, &len)) != EC_OK) return st;
+    }
+    struct Call {
+        int32_t ns, nsc, nst;
+        ec_dtype dt[4];
+        ec_value sc[8];
+        ec_expr_step steps[16];
+        bool masked;
+        std::vector<const void*> p[4];
+        std::vector<const uint8_t*> m[4];
+        std::vector<size_t> n;
+        std::vector<double*> out;
+        std::vector<uint8_t*> om;
+    };
+    auto c = std::make_shared<Call>();
+    c->ns = n_streams; c->nsc = n_scalars; c->nst = n_steps;
+    c->masked = masks_or_null != nullptr;
+    for (int k = 0; k < n_streams; ++k) {
+        c->dt[k] = dt[k];
+        if (!p[k] || (c->masked && !masks_or_null[k])) return set_error(EC_ERR_ARG, "ec_sharded_expr: stream %d has no pointer array", k);
+        if ((st = check_shard_ptrs(g, "ec_sharded_expr", "p[k]", p[k], n)) != EC_OK) return st;
+        c->p[k] = copy_n(p[k], g->n);
+        if (c->masked) {
+            if ((st = check_shard_ptrs(g, "ec_sharded_expr", "masks[k]", reinterpret_cast<const void* const*>(masks_or_null[k]), n)) != EC_OK) return st;
+            c->m[k] = copy_n(masks_or_null[k], g->n);
+        }
+    }
+    for (int k = 0; k < n_scalars; ++k) c->sc[k] = scalars[k];
+    for (int k = 0; k < n_steps; ++k) c->steps[k] = steps[k];
+    if ((st = check_shard_ptrs(g, "ec_sharded_expr", "out", reinterpret_cast<const void* const*>(out), n)) != EC_OK) return st;
+    c->n = copy_n(n, g->n);
+    c->out = copy_n(out, g->n);
+    if (out_mask_or_null) {
+        if ((st = check_shard_ptrs(g, "ec_sharded_expr", "out_mask", reinterpret_cast<const void* const*>(out_mask_or_null), n)) != EC_OK) return st;
+        c->om = copy_n(out_mask_or_null, g->n);
+    }
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    return post_each_shard(g, [g, c](int i) {
+        const void* pi[4] = {nullptr, nullptr, nullptr, nullptr};
+        const uint8_t* mi[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < c->ns; ++k) {
+            pi[k] = c->p[k][i];
+            if (c->masked) mi[k] = c->m[k][i];
+        }
+        if (c->masked) return ec_masked_expr(c->dt, pi, mi, c->ns, c->sc, c->nsc, c->steps, c->nst, c->n[i], c->out[i], c->om[i], g->streams[i]);
+        return ec_expr(c->dt, pi, c->ns, c->sc, c->nsc, c->steps, c->nst, c->n[i], c->out[i], g->streams[i]);
+    });
+}
+
 // ---- reductions: synchronous, phased (see the head of this file)
 extern "C" ec_status ec_sharded_min_max(ec_shard_group* g, ec_dtype t, const void* const* p, const uint8_t* const* masks_or_null,
                                         const size_t* n, ec_value* mn, ec_value* mx) {

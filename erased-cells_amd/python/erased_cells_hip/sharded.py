@@ -193,6 +193,25 @@ class ShardGroup:
         check(lib().ec_sharded_binop(self.handle, op, l.ct, l.ptrs, r.ct, r.ptrs, (C.c_size_t * self.n)(*l.lens), out.ptrs))
         return out
 
+    def program(self, streams, scalars, steps, masks=None):
+        """An expression program (`fused.program`: steps `(op, a, b, dst)`) on every shard, fire-and-forget: `streams` up to four
+        identically sharded buffers, `masks` (optional) one sharded mask per stream.  Returns the f64 result, or
+        `(result, mask)` with `masks`."""
+        from ._ffi import EcExprStep, PVP
+        lens = streams[0].lens
+        assert all(b.lens == lens for b in streams), "operands must be sharded identically"
+        k = len(streams)
+        dt = (C.c_uint8 * k)(*[b.ct for b in streams])
+        p = (PVP * k)(*[C.cast(b.ptrs, PVP) for b in streams])
+        m = (PVP * k)(*[C.cast(b.ptrs, PVP) for b in masks]) if masks is not None else None
+        sc = (EcValue * max(1, len(scalars)))(*[B.CellValue.new(x).to_ec() for x in scalars])
+        st = (EcExprStep * len(steps))(*[EcExprStep(*q) for q in steps])
+        out = self.alloc(B.Float64, lens)
+        om = self.alloc(B.UInt8, lens) if masks is not None else None
+        check(lib().ec_sharded_expr(self.handle, dt, p, m, k, sc, len(scalars), st, len(steps), (C.c_size_t * self.n)(*lens), out.ptrs,
+                                    om.ptrs if om is not None else None))
+        return out if om is None else (out, om)
+
     def min_max(self, sb: ShardedBuffer, mask: ShardedBuffer = None):
         mn, mx = EcValue(), EcValue()
         check(lib().ec_sharded_min_max(self.handle, sb.ct, sb.ptrs, mask.ptrs if mask is not None else None,

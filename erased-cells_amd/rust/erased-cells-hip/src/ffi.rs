@@ -178,6 +178,10 @@ extern "C" {
                             p: *const *const *const c_void, masks_or_null: *const *const *const u8,
                             scalars_or_null: *const ec_value, n: *const usize, out: *const *mut f64,
                             out_mask_or_null: *const *mut u8) -> ec_status;
+    pub fn ec_sharded_expr(g: *mut ec_shard_group, dt: *const ec_dtype, p: *const *const *const c_void,
+                           masks_or_null: *const *const *const u8, n_streams: i32, scalars: *const ec_value, n_scalars: i32,
+                           steps: *const ec_expr_step, n_steps: i32, n: *const usize, out: *const *mut f64,
+                           out_mask_or_null: *const *mut u8) -> ec_status;
     pub fn ec_sharded_min_max(g: *mut ec_shard_group, t: ec_dtype, p: *const *const c_void,
                               masks_or_null: *const *const u8, n: *const usize, mn: *mut ec_value,
                               mx: *mut ec_value) -> ec_status;

@@ -340,6 +340,13 @@ ec_status ec_sharded_fused(ec_shard_group *g, ec_op o1, ec_op o2, ec_op o3, cons
                            const void *const *const p[4], const uint8_t *const *const masks_or_null[4],
                            const ec_value *scalars_or_null, const size_t *n, double *const *out,
                            uint8_t *const *out_mask_or_null);
+/* Expression programs (ec_expr / ec_masked_expr) on every shard: p[k] (and masks_or_null[k]) is stream k's per-shard
+ * pointer array; masks_or_null / out_mask_or_null both given or both NULL.  A malformed program is EC_ERR_ARG on the
+ * calling thread, before anything is posted.  Fire-and-forget. */
+ec_status ec_sharded_expr(ec_shard_group *g, const ec_dtype *dt, const void *const *const *p,
+                          const uint8_t *const *const *masks_or_null, int32_t n_streams, const ec_value *scalars,
+                          int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps, const size_t *n,
+                          double *const *out, uint8_t *const *out_mask_or_null);
 /* BufferOps::min_max (src/buffer.rs:169-173; masked: src/masked/masked_buffer.rs:208-217) of the whole raster:
  * ec_min_max_keys per shard, one all-reduce(MAX) of the 16-byte keys, decode.  masks_or_null == NULL: unmasked.
  * Synchronous result. */

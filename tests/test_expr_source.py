@@ -75,3 +75,28 @@ def test_generated_sources_compile_for_gfx950():
     ec.fused.program_source([ec.Float64], 8, long, arch="gfx950")
     with pytest.raises(Exception, match="targets gfx950"):
         ec.fused.program_source([ec.UInt16], 1, [(ec.ADD, S(0), K(0), 0)], arch="gfx000-no-such-processor")
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc is not installed here")
+@pytest.mark.timeout(300)
+def test_generated_kernel_keeps_the_load_policy_in_the_machine_code(tmp_path):
+    """The generated kernel in gfx950 assembly (hipcc, the flags the library gives hiprtc): every global load and store of the
+    diagnostic source carries `nt` — the 1-byte streams included, which travel as 16-bit words because hipcc drops the flag
+    from <N x i8> loads — no scratch, and no vector-memory access inside the steps."""
+    import re
+    import subprocess
+    src = ec.fused.program_source([ec.UInt8, ec.Int8, ec.UInt16, ec.Float64], 4, [(ec.SUB, S(0), S(1), 0), (ec.MUL, R(0), K(0), 0), (ec.ADD, S(2), R(0), 1),
+                                                                               (ec.DIV, R(1), S(3), 0), (ec.ADD, R(0), K(3), 2)])
+    f = tmp_path / "k.hip"
+    f.write_text("#include <hip/hip_runtime.h>\n" + src)
+    asm = tmp_path / "k.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--cuda-device-only",
+                    "-S", "-o", str(asm), str(f)], check=True, capture_output=True)
+    text = asm.read_text()
+    body = text[text.index("\nec_expr_jit:"):]
+    body = body[:body.index("s_endpgm")]
+    mem = [l.strip() for l in body.split("\n") if re.match(r"\s*global_(load|store)", l)]
+    assert len(mem) >= 10, mem
+    assert all(l.endswith(" nt") for l in mem), [l for l in mem if not l.endswith(" nt")]
+    assert any("global_load_ushort" in l for l in mem), "a pair of 1-byte cells is one 16-bit word"
+    assert "scratch_" not in body and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", text)

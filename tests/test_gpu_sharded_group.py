@@ -486,6 +486,33 @@ def test_config5_ndvi_in_one_process_over_a_shard_group(ec, golden_dir, G):
         nf, rf = eco.f_convert(nir_h.ravel(), eco.F32), eco.f_convert(red_h.ravel(), eco.F32)
         exp = eco.f_binop(eco.DIV, eco.f_binop(eco.SUB, nf, rf), eco.f_binop_scalar(eco.ADD, nf, eco.Value.of(eco.F64, 2.5)))
         assert np.array_equal(g.gather(out2).view(np.uint64), exp.view(np.uint64))
+        # an expression program fanned out by the library: EVI-shaped, (nir - red) * 2.5 / (nir + 6 red + 1), masked and plain
+        E = ec._ffi
+        S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+        prog = [(ec.SUB, S(0), S(1), 0), (ec.MUL, R(0), K(0), 0), (ec.MUL, S(1), K(1), 1), (ec.ADD, S(0), R(1), 1), (ec.ADD, R(1), K(2), 1),
+                (ec.DIV, R(0), R(1), 0)]
+        st = (E.EcExprStep * len(prog))(*[E.EcExprStep(*q) for q in prog])
+        ks = (E.EcValue * 3)(*[ec.CellValue.new(x).to_ec() for x in (2.5, 6.0, 1.0)])
+        dt2 = (C.c_uint8 * 2)(ec.UInt16, ec.Float32)
+        p2 = (PVP * 2)(C.cast(nir.ptrs, PVP), C.cast(red_f.ptrs, PVP))
+        m2 = (PVP * 2)(C.cast(nir_m2.ptrs, PVP), C.cast(red_m2.ptrs, PVP))
+        chk(L.ec_sharded_expr(g.handle, dt2, p2, None, 2, ks, 3, st, len(prog), n_arr, out2.ptrs, None))
+        nh = nir_h.ravel()
+        full = lambda c: np.full(nh.size, c)  # noqa: E731
+        top = eco.f_binop(eco.MUL, eco.f_binop(eco.SUB, nh, rf), full(2.5))
+        bot = eco.f_binop(eco.ADD, eco.f_binop(eco.ADD, nh, eco.f_binop(eco.MUL, rf, full(6.0))), full(1.0))
+        exp = eco.f_binop(eco.DIV, top, bot)
+        assert np.array_equal(g.gather(out2).view(np.uint64), exp.view(np.uint64))
+        chk(L.ec_sharded_expr(g.handle, dt2, p2, m2, 2, ks, 3, st, len(prog), n_arr, t_sub.ptrs, m_sub.ptrs))
+        assert np.array_equal(g.gather(t_sub).view(np.uint64), exp.view(np.uint64)) and g.counts(m_sub) == (31430, 4)
+        bad = (E.EcExprStep * 1)(E.EcExprStep(ec.ADD, S(0), R(2), 0))  # register 2 read before any step wrote it: refused on the calling thread
+        assert L.ec_sharded_expr(g.handle, dt2, p2, None, 2, ks, 3, bad, 1, n_arr, out2.ptrs, None) == E.EC_ERR_ARG
+        assert L.ec_sharded_expr(g.handle, dt2, p2, m2, 2, ks, 3, st, len(prog), n_arr, out2.ptrs, None) == E.EC_ERR_ARG  # masks without out_mask
+        g.sync()  # nothing deferred
+        via_mirror, via_mirror_mask = g.program([nir, red_f], [2.5, 6.0, 1.0], prog, masks=[nir_m2, red_m2])
+        assert np.array_equal(g.gather(via_mirror).view(np.uint64), exp.view(np.uint64)) and g.counts(via_mirror_mask) == (31430, 4)
+        via_mirror.free()
+        via_mirror_mask.free()
         for b in (red_m2, nir_m2, m_sub, m_add, m_div, t_sub, t_add, out2):
             b.free()
         mn, mx = g.min_max(out, out_m)
