@@ -176,12 +176,12 @@ def test_rust_extern_block_declares_every_entry_point():
     assert {k: argc(v) for k, v in c_decls.items()} == {k: argc(v) for k, v in r_decls.items()}
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="quick"):
     import subprocess
-    exe = str(tmp_path / "quick_c")
+    exe = str(tmp_path / (name + "_c"))
     libdir = os.path.join(ROOT, "erased-cells_amd")
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
-                        os.path.join(ROOT, "examples", "quick.c"), "-L" + libdir, "-lerased_cells_hip",
+                        os.path.join(ROOT, "examples", name + ".c"), "-L" + libdir, "-lerased_cells_hip",
                         "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
@@ -190,6 +190,17 @@ def _build_c_example(tmp_path):
 def test_header_is_plain_c99_and_links_from_c(tmp_path):
     """The drop-in boundary is a C ABI: the header compiles as pedantic C99 and a C program links against the .so."""
     _build_c_example(tmp_path)
+    _build_c_example(tmp_path, "evi")
+
+
+@pytest.mark.gpu
+def test_evi_expression_program_from_plain_c(tmp_path):
+    """examples/evi.c: an eight-operator tree as one ec_expr call from C equals the eager chain of the same operators bit for
+    bit, interpreted and compiled for itself."""
+    import subprocess
+    r = subprocess.run([_build_c_example(tmp_path, "evi")], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "one pass == eight passes; interpreted launches 1, compiled launches 1" in r.stdout
 
 
 @pytest.mark.gpu
