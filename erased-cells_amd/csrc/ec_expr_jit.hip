@@ -232,6 +232,7 @@ ec_status expr_jit_compile(const std::string& source, const std::string& arch, s
 namespace {
 
 enum : int { kNew = 0, kCompiling = 1, kReady = 2, kFailed = 3 };
+constexpr size_t kMaxPrograms = 4096;  // cache entries (a code object is ≈ 10 KB)
 
 struct Entry {
     std::atomic<int> state{kNew};
@@ -331,12 +332,14 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, hipStream_t
     std::shared_ptr<Entry> e;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        auto& slot = g_cache[key_of(ea, arch)];
-        if (!slot) {
-            slot = std::make_shared<Entry>();
-            slot->arch = arch;
+        const std::string key = key_of(ea, arch);
+        auto it = g_cache.find(key);
+        if (it == g_cache.end()) {
+            if (g_cache.size() >= kMaxPrograms) return EC_OK;  // a process that keeps inventing programs: the rest are interpreted
+            it = g_cache.emplace(key, std::make_shared<Entry>()).first;
+            it->second->arch = arch;
         }
-        e = slot;
+        e = it->second;
     }
     int state = e->state.load(std::memory_order_acquire);
     if (state == kNew) {

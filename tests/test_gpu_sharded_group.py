@@ -513,6 +513,22 @@ def test_config5_ndvi_in_one_process_over_a_shard_group(ec, golden_dir, G):
         assert np.array_equal(g.gather(via_mirror).view(np.uint64), exp.view(np.uint64)) and g.counts(via_mirror_mask) == (31430, 4)
         via_mirror.free()
         via_mirror_mask.free()
+        # the compiled form from the group's launch threads at once (expr_jit = 2: the first thread to arrive compiles, the
+        # others wait for it; one module load per device)
+        chk(L.ec_tune_set(b"expr_jit", 2))
+        try:
+            prog2 = prog[:-1] + [(ec.DIV, R(1), R(0), 3)]  # a program no other test has compiled
+            v = C.c_int64(0)
+            chk(L.ec_stat_get(b"expr_jit_launches", C.byref(v)))
+            before = v.value
+            compiled = g.program([nir, red_f], [2.5, 6.0, 1.0], prog2)
+            g.sync()
+            chk(L.ec_stat_get(b"expr_jit_launches", C.byref(v)))
+            assert v.value == before + G
+            assert np.array_equal(g.gather(compiled).view(np.uint64), eco.f_binop(eco.DIV, bot, top).view(np.uint64))
+            compiled.free()
+        finally:
+            chk(L.ec_tune_set(b"expr_jit", 1))
         for b in (red_m2, nir_m2, m_sub, m_add, m_div, t_sub, t_add, out2):
             b.free()
         mn, mx = g.min_max(out, out_m)
