@@ -93,3 +93,72 @@ def test_crate_is_named_like_the_reference_library_and_carries_its_macro():
     # no foreign communicator in the sharded API any more
     sh = open(os.path.join(CRATE, "sharded.rs")).read()
     assert "rccl_comm: *mut c_void" not in sh and "ec_comm_init_rank" in sh and "ec_shard_group_create" in sh
+
+
+def _strip_rust(text: str) -> str:
+    """Rust source with comments, string / char literals and lifetimes blanked (enough of a lexer for the checks below)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            depth, i = 1, i + 2
+            while i < n and depth:
+                if text.startswith("/*", i):
+                    depth, i = depth + 1, i + 2
+                elif text.startswith("*/", i):
+                    depth, i = depth - 1, i + 2
+                else:
+                    i += 1
+        elif c == '"' or (c == "r" and re.match(r'r#*"', text[i:])):
+            if c == "r":
+                m = re.match(r'r(#*)"', text[i:])
+                end = text.find('"' + m.group(1), i + len(m.group(0)))
+                i = n if end < 0 else end + 1 + len(m.group(1))
+            else:
+                i += 1
+                while i < n and text[i] != '"':
+                    i += 2 if text[i] == "\\" else 1
+                i += 1
+            out.append('""')
+        elif c == "'":
+            m = re.match(r"'(\\.[^']*|[^'\\])'", text[i:])  # a char literal; anything else is a lifetime
+            if m:
+                i += len(m.group(0))
+                out.append("' '")
+            else:
+                i += 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def test_rust_sources_are_balanced_and_call_only_declared_ffi_items():
+    """No rustc here, so the cheapest classes of breakage are held by text: every bracket of every source file closes in
+    order, and every `ec_*` name a module uses is declared in ffi.rs (a call to an entry point the header has but ffi.rs
+    lacks — or a typo — would only show at the user's first `cargo build`)."""
+    src = CRATE
+    ffi = _strip_rust(open(os.path.join(src, "ffi.rs")).read())
+    declared = set(re.findall(r"\b(?:fn|struct|type|const|static)\s+(ec_\w+|EC_\w+)", ffi))
+    assert {"ec_binop", "ec_expr", "ec_value", "ec_expr_step", "EC_ADD", "ec_expr_reg"} <= declared
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for name in sorted(os.listdir(src)):
+        if not name.endswith(".rs"):
+            continue
+        text = _strip_rust(open(os.path.join(src, name)).read())
+        stack = []
+        for k, c in enumerate(text):
+            if c in "([{":
+                stack.append((c, k))
+            elif c in ")]}":
+                assert stack and stack[-1][0] == pairs[c], f"{name}: unbalanced '{c}' near: {text[max(0, k - 60):k + 20]!r}"
+                stack.pop()
+        assert not stack, f"{name}: unclosed '{stack[-1][0]}' near: {text[stack[-1][1]:stack[-1][1] + 60]!r}"
+        if name != "ffi.rs":
+            used = set(re.findall(r"\b(ec_[a-z0-9_]+|EC_[A-Z0-9_]+)\b", text))
+            local = set(re.findall(r"\b(?:fn|let|mod|struct|type|const)\s+(ec_\w+|EC_\w+)", text))
+            unknown = used - declared - local
+            assert not unknown, f"{name} uses {sorted(unknown)}: not declared in ffi.rs"
