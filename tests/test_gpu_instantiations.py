@@ -668,11 +668,23 @@ def test_expr_compiled_form_equals_the_interpreter_and_the_oracle(ec, pool):
         g.replay()
         torch.cuda.synchronize()
         assert _stat(ec, b"expr_interp_launches") == i0 + 1, "a program first met inside a capture must be interpreted"
+        h = host[eco.U16][:N]
+        exp = eco.f_binop(eco.SUB, eco.f_binop(eco.MUL, h, np.full(N, 123.25)), h)
+        assert_f64_bits_equal(out.to_numpy(), exp)
+        # once its module is loaded (one launch outside a capture), the compiled kernel is what a capture records
+        chk(L.ec_expr(dt, p, 1, sc, 1, st, 2, N, out.mem.ptr, cap.cuda_stream))
+        cap.synchronize()
+        j0 = _stat(ec, b"expr_jit_launches")
+        out2 = ec.CellBuffer.empty(N, ec.Float64)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=cap):
+            chk(L.ec_expr(dt, p, 1, sc, 1, st, 2, N, out2.mem.ptr, cap.cuda_stream))
+        assert _stat(ec, b"expr_jit_launches") == j0 + 1
+        g2.replay()
+        torch.cuda.synchronize()
+        assert_f64_bits_equal(out2.to_numpy(), exp)
     finally:
         L.ec_tune_set(b"expr_jit", 1)
-    h = host[eco.U16][:N]
-    exp = eco.f_binop(eco.SUB, eco.f_binop(eco.MUL, h, np.full(N, 123.25)), h)
-    assert_f64_bits_equal(out.to_numpy(), exp)
 
 
 def test_expr_background_compile_takes_over_once_a_program_has_run_long_enough(ec):
