@@ -866,6 +866,118 @@ inline MaskedCellBuffer program(const std::vector<const MaskedCellBuffer*>& stre
     return MaskedCellBuffer(std::move(out), std::move(om));
 }
 
+
+// Operator syntax for trees of ANY depth: `tree(nir)` wraps a buffer so that + - * / build a run-time operator tree, with
+// buffers (all plain or all masked) and scalars as leaves on either side; `eval()` schedules it onto the four registers
+// of an expression program — post-order, the sub-tree that needs more registers first (Sethi-Ullman), a register freed as
+// soon as its value is consumed — and runs it as ONE ec_expr launch.  A tree that needs more than 4 distinct buffers, 8
+// scalars, 16 operators or 4 live temporaries is cut: its two sub-trees are evaluated first (each again as far as it
+// goes) and combined with one operator.  Bit-identical to the same operators applied eagerly, in the same order.
+//   auto evi = ((tree(nir) - red) * 2.5 / (tree(nir) + tree(red) * 6.0 - tree(blue) * 7.5 + 1.0)).eval();
+template <typename B>
+class Expr {
+    struct Node {
+        ec_op op = EC_OP_NONE;  // EC_OP_NONE: a leaf
+        std::shared_ptr<const Node> l, r;
+        const B* buf = nullptr;  // leaf: a buffer, or
+        CellValue scalar;        //       a scalar
+        std::shared_ptr<const B> owned;  // a temporary that a cut produced (kept alive by the tree)
+    };
+    std::shared_ptr<const Node> n_;
+    explicit Expr(std::shared_ptr<const Node> n) : n_(std::move(n)) {}
+    static std::shared_ptr<const Node> leaf(const B& b) { auto n = std::make_shared<Node>(); n->buf = &b; return n; }
+    static std::shared_ptr<const Node> leaf(std::shared_ptr<const B> b) { auto n = std::make_shared<Node>(); n->buf = b.get(); n->owned = std::move(b); return n; }
+
+    struct Compiler {
+        std::vector<const B*> streams;
+        std::vector<CellValue> scalars;
+        std::vector<ec_expr_step> steps;
+        bool free_[4] = {true, true, true, true};
+        bool overflow = false;
+        static int need(const Node& t) {
+            if (t.op == EC_OP_NONE) return 0;
+            const int l = need(*t.l), r = need(*t.r);
+            return l != r ? std::max(1, std::max(l, r)) : (l ? l + 1 : 1);
+        }
+        int8_t operand(const Node& t) {
+            if (t.op != EC_OP_NONE) return emit(t);
+            if (t.buf) {
+                for (size_t i = 0; i < streams.size(); ++i)
+                    if (streams[i] == t.buf) return stream(int(i));
+                if (streams.size() == EC_EXPR_MAX_STREAMS) { overflow = true; return 0; }
+                streams.push_back(t.buf);
+                return stream(int(streams.size()) - 1);
+            }
+            if (scalars.size() == EC_EXPR_MAX_SCALARS) { overflow = true; return 0; }
+            scalars.push_back(t.scalar);
+            return fused::scalar(int(scalars.size()) - 1);
+        }
+        int8_t emit(const Node& t) {
+            int8_t a, b;
+            if (need(*t.r) > need(*t.l)) { b = operand(*t.r); a = operand(*t.l); }
+            else { a = operand(*t.l); b = operand(*t.r); }
+            if (overflow) return 0;
+            for (int8_t ref : {a, b})  // operands that are registers are dead after this step
+                if (ref >= reg(0) && ref < fused::scalar(0)) free_[ref - reg(0)] = true;
+            int dst = -1;
+            for (int k = 0; k < 4 && dst < 0; ++k) if (free_[k]) dst = k;
+            if (dst < 0 || steps.size() == EC_EXPR_MAX_STEPS) { overflow = true; return 0; }
+            free_[dst] = false;
+            steps.push_back(ec_expr_step{static_cast<int8_t>(t.op), a, b, static_cast<int8_t>(dst)});
+            return reg(dst);
+        }
+    };
+    static bool has_buffer(const Node& t) { return t.op == EC_OP_NONE ? t.buf != nullptr : has_buffer(*t.l) || has_buffer(*t.r); }
+    static CellValue fold(const Node& t) {  // a sub-tree of scalars only: host arithmetic (impl $trt for CellValue, src/value.rs:207)
+        if (t.op == EC_OP_NONE) return t.scalar;
+        const CellValue a = fold(*t.l), b = fold(*t.r);
+        return t.op == EC_ADD ? a + b : t.op == EC_SUB ? a - b : t.op == EC_MUL ? a * b : a / b;
+    }
+    static B run(const Node& t) {
+        if (t.op == EC_OP_NONE) throw Error(EC_ERR_ARG, "fused::Expr::eval: the tree is a single leaf");
+        Compiler c;
+        c.emit(t);
+        if (!c.overflow && !c.streams.empty()) return program(c.streams, c.scalars, c.steps);
+        // cut: both sub-trees first, then one operator
+        auto side = [](const std::shared_ptr<const Node>& s) -> std::shared_ptr<const Node> {
+            if (s->op == EC_OP_NONE) return s;
+            if (!has_buffer(*s)) { auto n = std::make_shared<Node>(); n->scalar = fold(*s); return n; }
+            return leaf(std::make_shared<const B>(run(*s)));
+        };
+        Node top;
+        top.op = t.op;
+        top.l = side(t.l);
+        top.r = side(t.r);
+        Compiler two;
+        two.emit(top);
+        if (two.overflow || two.streams.empty()) throw Error(EC_ERR_ARG, "fused::Expr::eval: the tree has no buffer operand");
+        return program(two.streams, two.scalars, two.steps);
+    }
+    static Expr node(ec_op op, const Expr& a, const Expr& b) {
+        auto n = std::make_shared<Node>();
+        n->op = op; n->l = a.n_; n->r = b.n_;
+        return Expr(std::move(n));
+    }
+
+public:
+    Expr(const B& b) : n_(leaf(b)) {}  // the buffer must outlive the expression
+    Expr(const CellValue& v) { auto n = std::make_shared<Node>(); n->scalar = v; n_ = std::move(n); }
+    template <typename T, typename = decltype(CellEncoding<T>::cell_type())>
+    Expr(T v) : Expr(CellValue(v)) {}
+    B eval() const { return run(*n_); }
+#define EC_EXPR_OP(SYM, OPC)                                                                             \
+    friend Expr operator SYM(const Expr& a, const Expr& b) { return node(OPC, a, b); }                   \
+    friend Expr operator SYM(const Expr& a, const B& b) { return node(OPC, a, Expr(b)); }                \
+    friend Expr operator SYM(const B& a, const Expr& b) { return node(OPC, Expr(a), b); }                \
+    template <typename T, typename = decltype(CellEncoding<T>::cell_type())>                             \
+    friend Expr operator SYM(const Expr& a, T b) { return node(OPC, a, Expr(CellValue(b))); }            \
+    template <typename T, typename = decltype(CellEncoding<T>::cell_type())>                             \
+    friend Expr operator SYM(T a, const Expr& b) { return node(OPC, Expr(CellValue(a)), b); }
+    EC_EXPR_OP(+, EC_ADD) EC_EXPR_OP(-, EC_SUB) EC_EXPR_OP(*, EC_MUL) EC_EXPR_OP(/, EC_DIV)
+#undef EC_EXPR_OP
+};
+template <typename B> inline Expr<B> tree(const B& b) { return Expr<B>(b); }
+
 }  // namespace fused
 
 // ---------------------------------------------------------------- one process, all GPUs of the node

@@ -431,6 +431,16 @@ static void gdal_tests(const std::string& data_dir) {
         MaskedCellBuffer mevi = program(std::vector<const MaskedCellBuffer*>{&mnir, &mred, &mr32}, k, evi);
         CHECK(mevi == ((mnir - mred) * 2.5) / (((mnir + mred * 6.0) - mr32 * 7.5) + 1.0));
         CHECK_THROWS(Error, program(std::vector<const CellBuffer*>{&nir}, k, {{EC_ADD, stream(0), reg(0), 0}}));  // register read before written
+        // the same tree in operator syntax: scheduled onto the program's registers, one launch
+        CHECK(((tree(nir) - red) * 2.5 / (tree(nir) + tree(red) * 6.0 - tree(r32) * 7.5 + 1.0)).eval() == evi_eager);
+        CHECK((((tree(mnir) - mred) * 2.5) / (((tree(mnir) + tree(mred) * 6.0) - tree(mr32) * 7.5) + 1.0)).eval() == mevi);
+        CHECK((1.0 - tree(nir) / (tree(red) + 0.5)).eval() == fused::program(std::vector<const CellBuffer*>{&nir, &red}, {1.0, 0.5},
+              {{EC_ADD, stream(1), scalar(1), 0}, {EC_DIV, stream(0), reg(0), 0}, {EC_SUB, scalar(0), reg(0), 0}}));  // scalar on the left
+        {   // five distinct buffers: more than the four streams of a program -> cut into sub-trees, same cells
+            CellBuffer r64 = red.convert(CellType::Float64), n32 = nir.convert(CellType::Float32), n64 = nir.convert(CellType::Float64);
+            CellBuffer wide = ((tree(nir) + red) * (tree(r32) - r64) / ((tree(n32) + 2.0) * 3.0 + n64)).eval();
+            CHECK(wide == ((nir + red) * (r32 - r64)) / (((n32 + 2.0) * 3.0) + n64));
+        }
     }
     // GdalND -> NoData<T> (src/gdal/mod.rs:49-70): range-checked
     CHECK(!nodata_from_f64<uint16_t>(std::nullopt, "u16").value().has_value());
