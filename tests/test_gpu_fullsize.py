@@ -186,3 +186,40 @@ def test_indexing_beyond_2_32_cells(ec):
     t, f = m.counts()
     assert t + f == n and abs(f / n - 1 / 256) < 1e-4
     assert ec.MaskedCellBuffer(a, m).min_max()[0].value == 1
+
+
+def test_evi_expression_program_16384sq_three_ways(ec):
+    """An eight-operator tree at raster scale (three 16384² u16 bands, bench.py's `--workload evi` inputs): the interpreter
+    kernel, the program compiled for itself and the eager chain of eight operators agree on every cell (compared on the
+    device), and the ends and the middle of the raster agree with the oracle's step-by-step evaluation."""
+    L, E, P = ec.lib(), ec._ffi, ec.fused
+    bands, seeds = [], (0x5EED0031, 0x5EED0032, 0x5EED0033)
+    ranges = [(2000 + 3000 * (2 - i), 20000 + 10000 * (2 - i)) for i in range(3)]
+    for seed, (lo, hi) in zip(seeds, ranges):
+        b = ec.CellBuffer.empty(N, ec.UInt16)
+        _chk(ec, L.ec_synth_fill(ec.UInt16, b.mem.ptr, N, seed, 0, float(lo), float(hi), None))
+        bands.append(b)
+    nir, red, blue = bands
+    S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+    prog = [(ec.SUB, S(0), S(1), 0), (ec.MUL, R(0), K(0), 0), (ec.MUL, S(1), K(1), 1), (ec.ADD, S(0), R(1), 1),
+            (ec.MUL, S(2), K(2), 2), (ec.SUB, R(1), R(2), 1), (ec.ADD, R(1), K(3), 1), (ec.DIV, R(0), R(1), 0)]
+    ks = [2.5, 6.0, 7.5, 1.0]
+    try:
+        L.ec_tune_set(b"expr_jit", 0)
+        interpreted = P.program(bands, ks, prog)
+        L.ec_tune_set(b"expr_jit", 2)
+        compiled = P.program(bands, ks, prog)
+    finally:
+        L.ec_tune_set(b"expr_jit", 1)
+    assert interpreted == compiled                      # ec_buffer_cmp: first differing cell on the device, none
+    eager = ((nir - red) * 2.5) / (((nir + red * 6.0) - blue * 7.5) + 1.0)
+    assert eager == compiled
+    del interpreted, eager
+    got = compiled.to_numpy()
+    for lo in (0, N // 2 - 12345, N - (1 << 20)):
+        hs = [eco.fill_u16(1 << 20, seed, base=lo, lo=r[0], hi=r[1]) for seed, r in zip(seeds, ranges)]
+        assert np.array_equal(hs[0], nir.shard(lo, 1 << 20).to_numpy())
+        f = lambda op, a, b: eco.f_binop(op, a, b if isinstance(b, np.ndarray) else np.full(1 << 20, float(b)))  # noqa: E731
+        exp = f(eco.DIV, f(eco.MUL, f(eco.SUB, hs[0], hs[1]), 2.5),
+                f(eco.ADD, f(eco.SUB, f(eco.ADD, hs[0], f(eco.MUL, hs[1], 6.0)), f(eco.MUL, hs[2], 7.5)), 1.0))
+        _assert_same_bits(got[lo:lo + (1 << 20)], exp)
