@@ -700,9 +700,9 @@ def test_expr_background_compile_takes_over_once_a_program_has_run_long_enough(e
     c0, f0 = _stat(ec, b"expr_jit_compiles"), _stat(ec, b"expr_jit_failures")
     first = P.program([x], scalars, steps).to_numpy()
     j0 = _stat(ec, b"expr_jit_launches")
-    for _ in range(8):  # 9 launches x 2^24 cells x 16 steps > 2^31
+    for _ in range(7):  # 8 launches x 2^24 cells x 16 steps = 2^31: the eighth (itself interpreted) hands the program to the compiler
         P.program([x], scalars, steps)
-    assert _stat(ec, b"expr_jit_launches") == j0, "nothing is compiled yet: the launches so far were interpreted"
+    assert _stat(ec, b"expr_jit_launches") == j0, "all eight launches were interpreted"
     deadline = time.time() + 60
     while _stat(ec, b"expr_jit_compiles") == c0 and _stat(ec, b"expr_jit_failures") == f0 and time.time() < deadline:
         time.sleep(0.05)
