@@ -519,6 +519,9 @@ def test_lazy_trees_deeper_than_two_levels_run_as_one_pass(ec, pool):
     exp = f(eco.DIV, f(eco.MUL, f(eco.SUB, hn, hr), 2.5),
             f(eco.ADD, f(eco.SUB, f(eco.ADD, hn, f(eco.MUL, hr, 6.0)), f(eco.MUL, hb, 7.5)), 1.0))
     assert_f64_bits_equal(evi.to_numpy(), exp)  # integer bands: no NaN can arise before the divide, none is left open
+    # the way a formula is usually written, scalars on the left (README): the same cells (products commute exactly)
+    evi_l = (2.5 * (L(nir) - red) / (L(nir) + 6.0 * L(red) - 7.5 * L(blue) + 1.0)).eval()
+    assert np.array_equal(bits_of(evi_l.to_numpy()), bits_of(evi.to_numpy()))
     # right-heavy two-operator tree: not a shape of the two-level kernel, one pass through the program kernel
     a, b, c = dev[eco.F32].shard(0, N), dev[eco.I16].shard(1, N), dev[eco.U8].shard(2, N)
     before = _pool_allocs(ec)
