@@ -1,0 +1,157 @@
+// ec_hostpipe.hip — host memory in, host memory out: an expression program streamed through the GPU.
+//
+// The reference's operands and results are `Vec`s in host memory (src/buffer.rs:12-55); a caller that keeps nothing
+// resident pays PCIe both ways — Σ sizeof(T) bytes per cell up and 8 bytes per cell down — and that, not the kernel, is
+// the bound (≈ 55 GB/s each way on this box: ≤ 7 Gcells/s for any f64-result operator, against 450-650 Gcells/s resident).
+// What the library can do is keep both directions of the link busy at once: ec_host_expr cuts the operands into chunks and
+// runs upload, kernel and download on three streams over double-buffered device staging, ordered by events.
+//
+// Page-locked host memory is what makes the copies asynchronous: ec_host_alloc / ec_host_free hand such memory out, and
+// buffers that are not page-locked yet are registered (hipHostRegister) for the duration of the call — pinning pages costs
+// about as much as one pass over them, so a caller who reuses its buffers should allocate them with ec_host_alloc.  If
+// registration is refused the copies go through the runtime's pageable path (correct, slower).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "ec_lattice.hpp"
+#include "ec_runtime.hpp"
+#include "erased_cells.h"
+
+using namespace ecd;
+
+extern "C" ec_status ec_host_alloc(void** hptr, size_t bytes) {
+    if (!hptr) return set_error(EC_ERR_ARG, "ec_host_alloc: null out pointer");
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    *hptr = nullptr;
+    if (bytes == 0) return EC_OK;
+    return check_hip(hipHostMalloc(hptr, bytes, hipHostMallocDefault), "hipHostMalloc");
+}
+
+extern "C" ec_status ec_host_free(void* hptr) { return hptr ? check_hip(hipHostFree(hptr), "hipHostFree") : EC_OK; }
+
+namespace {
+
+// Registers a host range for the life of the object unless it already is page-locked.
+struct Pinned {
+    void* p = nullptr;
+    bool ours = false;
+    void pin(const void* ptr, size_t bytes) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeHost) return;  // already page-locked
+        (void)hipGetLastError();  // "not a HIP pointer" is an answer, not a failure
+        if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) {
+            p = const_cast<void*>(ptr);
+            ours = true;
+        } else {
+            (void)hipGetLastError();  // refused (e.g. a read-only mapping): the runtime's pageable path will do
+        }
+    }
+    ~Pinned() {
+        if (ours) (void)hipHostUnregister(p);
+    }
+};
+
+struct Pipe {
+    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    void* stage[2] = {nullptr, nullptr};
+    ec_status open(size_t stage_bytes) {
+        for (hipStream_t* s : {&s_in, &s_cmp, &s_out}) {
+            ec_status st = check_hip(hipStreamCreateWithFlags(s, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+            if (st != EC_OK) return st;
+        }
+        for (int k = 0; k < 2; ++k) {
+            for (hipEvent_t* e : {&ev_in[k], &ev_cmp[k], &ev_out[k]}) {
+                ec_status st = check_hip(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreateWithFlags");
+                if (st != EC_OK) return st;
+            }
+            // from the library's stream-ordered pool: a second call finds the blocks of the first (hipMalloc + hipFree of two
+            // 370 MB slots cost ≈ 10 ms a call, a sixth of a 16384² divide's transfer time)
+            ec_status st = ec_alloc_async(&stage[k], stage_bytes, s_cmp);
+            if (st != EC_OK) return st;
+        }
+        return check_hip(hipStreamSynchronize(s_cmp), "hipStreamSynchronize");  // the blocks exist before the copy streams touch them
+    }
+    ~Pipe() {
+        for (hipStream_t s : {s_in, s_out, s_cmp})
+            if (s) (void)hipStreamSynchronize(s);
+        for (int k = 0; k < 2; ++k)
+            if (stage[k] && s_cmp) (void)ec_free_async(stage[k], s_cmp);
+        for (hipStream_t s : {s_in, s_cmp, s_out})
+            if (s) {
+                (void)hipStreamSynchronize(s);
+                (void)hipStreamDestroy(s);
+            }
+        for (int k = 0; k < 2; ++k)
+            for (hipEvent_t e : {ev_in[k], ev_cmp[k], ev_out[k]})
+                if (e) (void)hipEventDestroy(e);
+    }
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" ec_status ec_host_expr(const ec_dtype* dt, const void* const* p_host, int32_t n_streams, const ec_value* scalars, int32_t n_scalars,
+                                  const ec_expr_step* steps, int32_t n_steps, size_t n, double* out_host, size_t chunk_cells) {
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    {   // the program, refused before anything is allocated
+        size_t len = 0;
+        if ((st = ec_expr_source(dt, n_streams, n_scalars, steps, n_steps, nullptr, nullptr, 0, &len)) != EC_OK) return st;
+    }
+    if (n == 0) return EC_OK;
+    if (!p_host || !out_host) return set_error(EC_ERR_ARG, "ec_host_expr: null pointer");
+    for (int k = 0; k < n_streams; ++k)
+        if (!p_host[k]) return set_error(EC_ERR_ARG, "ec_host_expr: stream %d is null", k);
+    const size_t chunk = std::min(n, chunk_cells ? chunk_cells : size_t(1) << 25);
+    // one staging slot: the operands' chunks, then the f64 result, each on a 256-byte boundary
+    size_t off[5], bytes_per_cell[4] = {0, 0, 0, 0}, at = 0;
+    for (int k = 0; k < n_streams; ++k) {
+        bytes_per_cell[k] = ecl::size_of(dt[k]);
+        off[k] = at;
+        at = align_up(at + chunk * bytes_per_cell[k], 256);
+    }
+    off[4] = at;
+    at = align_up(at + chunk * sizeof(double), 256);
+    Pinned pins[5];
+    for (int k = 0; k < n_streams; ++k) pins[k].pin(p_host[k], n * bytes_per_cell[k]);
+    pins[4].pin(out_host, n * sizeof(double));
+    Pipe pipe;
+    if ((st = pipe.open(at)) != EC_OK) return st;
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    for (size_t c = 0; c < nchunks && st == EC_OK; ++c) {
+        const int k = static_cast<int>(c & 1);
+        const size_t lo = c * chunk, m = std::min(chunk, n - lo);
+        char* slot = static_cast<char*>(pipe.stage[k]);
+        // upload: once the kernel that last read this slot's operands has finished
+        st = check_hip(hipStreamWaitEvent(pipe.s_in, pipe.ev_cmp[k], 0), "hipStreamWaitEvent");
+        const void* dptr[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int j = 0; j < n_streams && st == EC_OK; ++j) {
+            dptr[j] = slot + off[j];
+            st = check_hip(hipMemcpyAsync(slot + off[j], static_cast<const char*>(p_host[j]) + lo * bytes_per_cell[j], m * bytes_per_cell[j],
+                                          hipMemcpyHostToDevice, pipe.s_in), "hipMemcpyAsync(H2D)");
+        }
+        if (st == EC_OK) st = check_hip(hipEventRecord(pipe.ev_in[k], pipe.s_in), "hipEventRecord");
+        // compute: once the operands are there and the slot's previous result has left for the host
+        if (st == EC_OK) st = check_hip(hipStreamWaitEvent(pipe.s_cmp, pipe.ev_in[k], 0), "hipStreamWaitEvent");
+        if (st == EC_OK) st = check_hip(hipStreamWaitEvent(pipe.s_cmp, pipe.ev_out[k], 0), "hipStreamWaitEvent");
+        double* dout = reinterpret_cast<double*>(slot + off[4]);
+        if (st == EC_OK) st = ec_expr(dt, dptr, n_streams, scalars, n_scalars, steps, n_steps, m, dout, pipe.s_cmp);
+        if (st == EC_OK) st = check_hip(hipEventRecord(pipe.ev_cmp[k], pipe.s_cmp), "hipEventRecord");
+        // download
+        if (st == EC_OK) st = check_hip(hipStreamWaitEvent(pipe.s_out, pipe.ev_cmp[k], 0), "hipStreamWaitEvent");
+        if (st == EC_OK) st = check_hip(hipMemcpyAsync(out_host + lo, dout, m * sizeof(double), hipMemcpyDeviceToHost, pipe.s_out), "hipMemcpyAsync(D2H)");
+        if (st == EC_OK) st = check_hip(hipEventRecord(pipe.ev_out[k], pipe.s_out), "hipEventRecord");
+    }
+    const std::string keep = st != EC_OK ? last_error_text() : std::string();
+    for (hipStream_t s : {pipe.s_in, pipe.s_cmp, pipe.s_out}) {
+        const ec_status w = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        if (st == EC_OK && w != EC_OK) st = w;
+    }
+    if (!keep.empty()) return set_error_text(st, keep);
+    return st;
+}

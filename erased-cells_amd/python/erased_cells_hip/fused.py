@@ -94,6 +94,41 @@ def program(streams, scalars, steps):
     return B.MaskedCellBuffer(out, om)
 
 
+def pinned_empty(n: int, dtype):
+    """A page-locked numpy array (`ec_host_alloc`): what `program_host` copies to and from without registering pages first.
+    The memory is returned to the system when the array (and every view of it) is garbage."""
+    import numpy as np
+    import weakref
+    dt = np.dtype(dtype)
+    p = C.c_void_p()
+    check(lib().ec_host_alloc(C.byref(p), max(1, n * dt.itemsize)))
+    buf = (C.c_char * max(1, n * dt.itemsize)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n)
+    weakref.finalize(buf, lib().ec_host_free, p)
+    return arr
+
+
+def program_host(arrays, scalars, steps, out=None, chunk_cells: int = 0):
+    """An expression program over HOST arrays (numpy, one per stream, any of the ten cell types), streamed through the GPU
+    in chunks with upload, kernel and download overlapped (`ec_host_expr`): what the reference's Vec-in / Vec-out operators
+    cost when nothing stays resident — PCIe-bound.  Returns (or fills `out`: a C-contiguous float64 array, ideally from
+    `pinned_empty`) the f64 result of min(len) cells."""
+    import numpy as np
+    from ._ffi import EcExprStep
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    n = min(a.size for a in arrays)
+    k = len(arrays)
+    dt = (C.c_uint8 * k)(*[B.cell_type_of(a.dtype) for a in arrays])
+    p = (C.c_void_p * k)(*[a.ctypes.data for a in arrays])
+    sc = (B.EcValue * max(1, len(scalars)))(*[B.CellValue.new(x).to_ec() for x in scalars])
+    st = (EcExprStep * len(steps))(*[EcExprStep(*s_) for s_ in steps])
+    if out is None:
+        out = np.empty(n, dtype=np.float64)
+    assert out.dtype == np.float64 and out.flags.c_contiguous and out.size >= n
+    check(lib().ec_host_expr(dt, p, k, sc, len(scalars), st, len(steps), n, out.ctypes.data, chunk_cells))
+    return out[:n]
+
+
 def program_source(cell_types, n_scalars, steps, arch=None) -> str:
     """The HIP source the library compiles for a program when it compiles it for itself (`ec_expr_source`; no GPU needed).
     With `arch` (e.g. "gfx950") the source is also compiled once with hiprtc; a failure raises with the compiler's log."""

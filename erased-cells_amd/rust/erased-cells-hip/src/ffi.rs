@@ -145,6 +145,10 @@ extern "C" {
                           out: *mut f64, out_mask: *mut u8, s: ec_stream) -> ec_status;
     pub fn ec_expr_source(dt: *const ec_dtype, n_streams: i32, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32,
                           arch_or_null: *const c_char, buf: *mut c_char, cap: usize, len: *mut usize) -> ec_status;
+    pub fn ec_host_alloc(hptr: *mut *mut c_void, bytes: usize) -> ec_status;
+    pub fn ec_host_free(hptr: *mut c_void) -> ec_status;
+    pub fn ec_host_expr(dt: *const ec_dtype, p_host: *const *const c_void, n_streams: i32, scalars: *const ec_value, n_scalars: i32,
+                        steps: *const ec_expr_step, n_steps: i32, n: usize, out_host: *mut f64, chunk_cells: usize) -> ec_status;
     pub fn ec_comm_get_unique_id(uid: *mut ec_comm_uid) -> ec_status;
     pub fn ec_comm_init_rank(uid: *const ec_comm_uid, n_ranks: i32, rank: i32, comm: *mut ec_comm) -> ec_status;
     pub fn ec_comm_init_all(devices: *const i32, n: i32, comms: *mut ec_comm) -> ec_status;

@@ -238,6 +238,20 @@ ec_status ec_masked_expr(const ec_dtype *dt, const void *const *p, const uint8_t
 ec_status ec_expr_source(const ec_dtype *dt, int32_t n_streams, int32_t n_scalars, const ec_expr_step *steps,
                          int32_t n_steps, const char *arch_or_null, char *buf, size_t cap, size_t *len);
 
+/* Host memory in, host memory out.  The reference's operands and results are Vecs in host memory
+ * (src/buffer.rs:12-55, impl $trt for &CellBuffer :324-352); a caller that keeps nothing resident is bound by PCIe —
+ * the operands' bytes up, 8 bytes per cell down — not by the kernel.  ec_host_expr evaluates an expression program
+ * (ec_expr: a single operator is a one-step program) over HOST arrays p_host[k] of n cells into out_host[0..n): chunks
+ * of `chunk_cells` cells (0 = 2^25), upload / kernel / download on three streams over double-buffered device staging,
+ * so both directions of the link are busy at once.  Page-locked buffers (ec_host_alloc) are copied asynchronously as
+ * they are; any other buffer is page-locked for the duration of the call (hipHostRegister: about one pass over the
+ * pages) and, if that is refused, copied through the runtime's pageable path.  Synchronous; uses its own streams. */
+ec_status ec_host_alloc(void **hptr, size_t bytes); /* page-locked host memory */
+ec_status ec_host_free(void *hptr);
+ec_status ec_host_expr(const ec_dtype *dt, const void *const *p_host, int32_t n_streams, const ec_value *scalars,
+                       int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps, size_t n, double *out_host,
+                       size_t chunk_cells);
+
 /* ---------------------------------------------------------------- *
  * min/max under the reference's total order (ints natural; floats total_cmp),
  * folded from (T::MAX, T::MIN) — src/buffer.rs:169-173, masked:

@@ -715,6 +715,39 @@ def test_expr_background_compile_takes_over_once_a_program_has_run_long_enough(e
     assert np.array_equal(bits_of(later.to_numpy()), bits_of(first))
 
 
+def test_host_to_host_expression_pipeline(ec):
+    """`ec_host_expr`: host arrays in, host array out, chunked with upload / kernel / download overlapped — pageable numpy
+    arrays (registered for the call), page-locked ones (`pinned_empty`), chunk sizes that do and do not divide the length,
+    one chunk, odd lengths; against the oracle's step-by-step evaluation; a malformed program is refused up front."""
+    P = ec.fused
+    n = (1 << 20) + 12345
+    hs = [rand_cells(ct, n, 9100 + ct) for ct in (eco.U16, eco.I8, eco.F32)]
+    S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+    steps = [(eco.SUB, S(0), S(1), 0), (eco.MUL, R(0), K(0), 0), (eco.ADD, S(2), R(0), 1), (eco.DIV, R(1), S(0), 0)]
+    exp, loose = _oracle_program(hs, [2.5], steps)
+    for chunk in (0, 1 << 18, 300001, n, 7):
+        if chunk == 7:  # many tiny chunks: only a prefix, or the test would take minutes
+            got = P.program_host([h[:1001] for h in hs], [2.5], steps, chunk_cells=7)
+            assert_f64_bits_equal(got, exp[:1001], nan_by_class_where=loose[:1001])
+            continue
+        got = P.program_host(hs, [2.5], steps, chunk_cells=chunk)
+        assert_f64_bits_equal(got, exp, nan_by_class_where=loose)
+    # page-locked operands and result
+    pinned = [P.pinned_empty(n, h.dtype) for h in hs]
+    for q, h in zip(pinned, hs):
+        q[:] = h
+    out = P.pinned_empty(n, np.float64)
+    out[:] = -1.0
+    got = P.program_host(pinned, [2.5], steps, out=out, chunk_cells=1 << 18)
+    assert got.ctypes.data == out.ctypes.data
+    assert_f64_bits_equal(out, exp, nan_by_class_where=loose)
+    # a single operator is a one-step program: the reference's quick example, host to host
+    q = P.program_host([np.array([1, 2, 3], np.uint8), np.array([2, 4, 6], np.uint16)], [0.5], [(eco.DIV, S(0), S(1), 0), (eco.MUL, R(0), K(0), 0)])
+    assert q.tolist() == [0.25, 0.25, 0.25]
+    with pytest.raises(Exception):
+        P.program_host(hs, [2.5], [(eco.ADD, S(0), R(1), 0)])  # register read before it is written
+
+
 def test_expr_rejects_malformed_programs(ec, pool):
     host, dev, _, _ = pool
     L, E = ec.lib(), ec._ffi
