@@ -867,6 +867,26 @@ inline MaskedCellBuffer program(const std::vector<const MaskedCellBuffer*>& stre
 }
 
 
+// Host memory in, host memory out (ec_host_expr): the same program over HOST arrays of n cells each — `arrays[k]` is
+// {cell type, pointer} — streamed through the GPU in chunks with upload, kernel and download overlapped; PCIe-bound
+// (≈ 6 Gcells/s at 16384² against ≈ 1.2 for from_vec + operator + to_vec).  Page-locked buffers (ec_host_alloc) are copied
+// as they are, others are registered for the duration of the call.
+inline std::vector<double> program_host(const std::vector<std::pair<CellType, const void*>>& arrays, size_t n,
+                                        const std::vector<CellValue>& scalars, const std::vector<ec_expr_step>& steps, size_t chunk_cells = 0) {
+    std::vector<ec_dtype> dt;
+    std::vector<const void*> p;
+    for (const auto& a : arrays) {
+        dt.push_back(static_cast<ec_dtype>(a.first));
+        p.push_back(a.second);
+    }
+    std::vector<ec_value> sc;
+    for (const CellValue& v : scalars) sc.push_back(v.raw());
+    std::vector<double> out(n);
+    check(ec_host_expr(dt.data(), p.data(), static_cast<int32_t>(arrays.size()), sc.data(), static_cast<int32_t>(sc.size()), steps.data(),
+                       static_cast<int32_t>(steps.size()), n, out.data(), chunk_cells));
+    return out;
+}
+
 // Operator syntax for trees of ANY depth: `tree(nir)` wraps a buffer so that + - * / build a run-time operator tree, with
 // buffers (all plain or all masked) and scalars as leaves on either side; `eval()` schedules it onto the four registers
 // of an expression program — post-order, the sub-tree that needs more registers first (Sethi-Ullman), a register freed as

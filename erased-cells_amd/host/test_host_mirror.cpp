@@ -431,6 +431,13 @@ static void gdal_tests(const std::string& data_dir) {
         MaskedCellBuffer mevi = program(std::vector<const MaskedCellBuffer*>{&mnir, &mred, &mr32}, k, evi);
         CHECK(mevi == ((mnir - mred) * 2.5) / (((mnir + mred * 6.0) - mr32 * 7.5) + 1.0));
         CHECK_THROWS(Error, program(std::vector<const CellBuffer*>{&nir}, k, {{EC_ADD, stream(0), reg(0), 0}}));  // register read before written
+        {   // host memory in, host memory out: the same program streamed through the GPU equals the resident result
+            const std::vector<uint16_t> hn = nir.to_vec<uint16_t>(), hr = red.to_vec<uint16_t>();
+            const std::vector<float> hf = r32.to_vec<float>();
+            const std::vector<double> streamed = program_host({{CellType::UInt16, hn.data()}, {CellType::UInt16, hr.data()}, {CellType::Float32, hf.data()}},
+                                                              hn.size(), k, evi, 4099);
+            CHECK(CellBuffer::from_vec(streamed) == evi_eager);
+        }
         // the same tree in operator syntax: scheduled onto the program's registers, one launch
         CHECK(((tree(nir) - red) * 2.5 / (tree(nir) + tree(red) * 6.0 - tree(r32) * 7.5 + 1.0)).eval() == evi_eager);
         CHECK((((tree(mnir) - mred) * 2.5) / (((tree(mnir) + tree(mred) * 6.0) - tree(mr32) * 7.5) + 1.0)).eval() == mevi);

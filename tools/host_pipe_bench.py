@@ -16,7 +16,7 @@ import erased_cells_hip as ec  # noqa: E402
 S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
 
 
-def timed(fn, reps=3):
+def timed(fn, reps=5):
     fn()
     t = []
     for _ in range(reps):
