@@ -95,33 +95,60 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
-extern "C" ec_status ec_host_expr(const ec_dtype* dt, const void* const* p_host, int32_t n_streams, const ec_value* scalars, int32_t n_scalars,
-                                  const ec_expr_step* steps, int32_t n_steps, size_t n, double* out_host, size_t chunk_cells) {
+// The pipeline behind ec_host_expr and ec_host_masked_expr.  Masked form (nodata != nullptr): per chunk, on the device,
+// mask_k = (stream k != nodata[k]) (from_vec_with_nodata, src/masked/masked_buffer.rs:62-71), the program with the AND of the
+// masks (impl $trt for &MaskedCellBuffer, :326-364), then out = mask ? value : *out_nodata (to_vec_with_nodata, :137-152) —
+// what travels back is still 8 bytes per cell (+ 1 when the caller wants the mask).
+static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void* const* p_host, const ec_value* const* nodata, int32_t n_streams,
+                               const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n, double* out_host,
+                               const double* out_nodata, uint8_t* out_mask_host, size_t chunk_cells) {
     ec_status st = ensure_ready();
     if (st != EC_OK) return st;
     {   // the program, refused before anything is allocated
         size_t len = 0;
         if ((st = ec_expr_source(dt, n_streams, n_scalars, steps, n_steps, nullptr, nullptr, 0, &len)) != EC_OK) return st;
     }
+    const bool masked = nodata != nullptr;
+    if (masked)
+        for (int k = 0; k < n_streams; ++k)
+            if (nodata[k] && nodata[k]->dtype != dt[k])
+                return set_error(EC_ERR_ARG, "%s: nodata[%d] has cell type %d, its stream %d", what, k, int(nodata[k]->dtype), int(dt[k]));
     if (n == 0) return EC_OK;
-    if (!p_host || !out_host) return set_error(EC_ERR_ARG, "ec_host_expr: null pointer");
+    if (!p_host || !out_host) return set_error(EC_ERR_ARG, "%s: null pointer", what);
     for (int k = 0; k < n_streams; ++k)
-        if (!p_host[k]) return set_error(EC_ERR_ARG, "ec_host_expr: stream %d is null", k);
+        if (!p_host[k]) return set_error(EC_ERR_ARG, "%s: stream %d is null", what, k);
     const size_t chunk = std::min(n, chunk_cells ? chunk_cells : size_t(1) << 25);
-    // one staging slot: the operands' chunks, then the f64 result, each on a 256-byte boundary
-    size_t off[5], bytes_per_cell[4] = {0, 0, 0, 0}, at = 0;
+    // one staging slot: the operands' chunks, the f64 result (and, masked: the streams' masks, the result's mask, the selected
+    // result), each on a 256-byte boundary
+    size_t off[4], off_out, off_mask[4] = {0, 0, 0, 0}, off_omask = 0, off_sel = 0, bytes_per_cell[4] = {0, 0, 0, 0}, at = 0;
     for (int k = 0; k < n_streams; ++k) {
         bytes_per_cell[k] = ecl::size_of(dt[k]);
         off[k] = at;
         at = align_up(at + chunk * bytes_per_cell[k], 256);
     }
-    off[4] = at;
+    off_out = at;
     at = align_up(at + chunk * sizeof(double), 256);
-    Pinned pins[5];
+    if (masked) {
+        for (int k = 0; k < n_streams; ++k) {
+            off_mask[k] = at;
+            at = align_up(at + chunk, 256);
+        }
+        off_omask = at;
+        at = align_up(at + chunk, 256);
+        off_sel = at;
+        at = align_up(at + chunk * sizeof(double), 256);
+    }
+    Pinned pins[6];
     for (int k = 0; k < n_streams; ++k) pins[k].pin(p_host[k], n * bytes_per_cell[k]);
     pins[4].pin(out_host, n * sizeof(double));
+    if (out_mask_host) pins[5].pin(out_mask_host, n);
     Pipe pipe;
     if ((st = pipe.open(at)) != EC_OK) return st;
+    ec_value sel{};
+    if (out_nodata) {
+        sel.dtype = EC_F64;
+        sel.v.f64 = *out_nodata;
+    }
     const size_t nchunks = (n + chunk - 1) / chunk;
     for (size_t c = 0; c < nchunks && st == EC_OK; ++c) {
         const int k = static_cast<int>(c & 1);
@@ -130,6 +157,7 @@ extern "C" ec_status ec_host_expr(const ec_dtype* dt, const void* const* p_host,
         // upload: once the kernel that last read this slot's operands has finished
         st = check_hip(hipStreamWaitEvent(pipe.s_in, pipe.ev_cmp[k], 0), "hipStreamWaitEvent");
         const void* dptr[4] = {nullptr, nullptr, nullptr, nullptr};
+        const uint8_t* dmask[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int j = 0; j < n_streams && st == EC_OK; ++j) {
             dptr[j] = slot + off[j];
             st = check_hip(hipMemcpyAsync(slot + off[j], static_cast<const char*>(p_host[j]) + lo * bytes_per_cell[j], m * bytes_per_cell[j],
@@ -139,12 +167,30 @@ extern "C" ec_status ec_host_expr(const ec_dtype* dt, const void* const* p_host,
         // compute: once the operands are there and the slot's previous result has left for the host
         if (st == EC_OK) st = check_hip(hipStreamWaitEvent(pipe.s_cmp, pipe.ev_in[k], 0), "hipStreamWaitEvent");
         if (st == EC_OK) st = check_hip(hipStreamWaitEvent(pipe.s_cmp, pipe.ev_out[k], 0), "hipStreamWaitEvent");
-        double* dout = reinterpret_cast<double*>(slot + off[4]);
-        if (st == EC_OK) st = ec_expr(dt, dptr, n_streams, scalars, n_scalars, steps, n_steps, m, dout, pipe.s_cmp);
+        double* dout = reinterpret_cast<double*>(slot + off_out);
+        const double* result = dout;
+        uint8_t* domask = reinterpret_cast<uint8_t*>(slot + off_omask);
+        if (!masked) {
+            if (st == EC_OK) st = ec_expr(dt, dptr, n_streams, scalars, n_scalars, steps, n_steps, m, dout, pipe.s_cmp);
+        } else {
+            for (int j = 0; j < n_streams && st == EC_OK; ++j) {
+                uint8_t* mk = reinterpret_cast<uint8_t*>(slot + off_mask[j]);
+                dmask[j] = mk;
+                st = ec_mask_from_nodata(dt[j], dptr[j], m, nodata[j], mk, pipe.s_cmp);
+            }
+            if (st == EC_OK) st = ec_masked_expr(dt, dptr, dmask, n_streams, scalars, n_scalars, steps, n_steps, m, dout, domask, pipe.s_cmp);
+            if (st == EC_OK && out_nodata) {
+                double* dsel = reinterpret_cast<double*>(slot + off_sel);
+                st = ec_mask_select(EC_F64, dout, domask, m, &sel, dsel, pipe.s_cmp);
+                result = dsel;
+            }
+        }
         if (st == EC_OK) st = check_hip(hipEventRecord(pipe.ev_cmp[k], pipe.s_cmp), "hipEventRecord");
         // download
         if (st == EC_OK) st = check_hip(hipStreamWaitEvent(pipe.s_out, pipe.ev_cmp[k], 0), "hipStreamWaitEvent");
-        if (st == EC_OK) st = check_hip(hipMemcpyAsync(out_host + lo, dout, m * sizeof(double), hipMemcpyDeviceToHost, pipe.s_out), "hipMemcpyAsync(D2H)");
+        if (st == EC_OK) st = check_hip(hipMemcpyAsync(out_host + lo, result, m * sizeof(double), hipMemcpyDeviceToHost, pipe.s_out), "hipMemcpyAsync(D2H)");
+        if (st == EC_OK && masked && out_mask_host)
+            st = check_hip(hipMemcpyAsync(out_mask_host + lo, domask, m, hipMemcpyDeviceToHost, pipe.s_out), "hipMemcpyAsync(D2H mask)");
         if (st == EC_OK) st = check_hip(hipEventRecord(pipe.ev_out[k], pipe.s_out), "hipEventRecord");
     }
     const std::string keep = st != EC_OK ? last_error_text() : std::string();
@@ -154,4 +200,17 @@ extern "C" ec_status ec_host_expr(const ec_dtype* dt, const void* const* p_host,
     }
     if (!keep.empty()) return set_error_text(st, keep);
     return st;
+}
+
+extern "C" ec_status ec_host_expr(const ec_dtype* dt, const void* const* p_host, int32_t n_streams, const ec_value* scalars, int32_t n_scalars,
+                                  const ec_expr_step* steps, int32_t n_steps, size_t n, double* out_host, size_t chunk_cells) {
+    return host_pipeline("ec_host_expr", dt, p_host, nullptr, n_streams, scalars, n_scalars, steps, n_steps, n, out_host, nullptr, nullptr, chunk_cells);
+}
+
+extern "C" ec_status ec_host_masked_expr(const ec_dtype* dt, const void* const* p_host, const ec_value* const* nodata, int32_t n_streams,
+                                         const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
+                                         double* out_host, const double* out_nodata_or_null, uint8_t* out_mask_host_or_null, size_t chunk_cells) {
+    if (!nodata) return set_error(EC_ERR_ARG, "ec_host_masked_expr: null nodata array (entries may be NULL: NoData::None)");
+    return host_pipeline("ec_host_masked_expr", dt, p_host, nodata, n_streams, scalars, n_scalars, steps, n_steps, n, out_host, out_nodata_or_null,
+                         out_mask_host_or_null, chunk_cells);
 }

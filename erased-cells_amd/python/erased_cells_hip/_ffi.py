@@ -91,6 +91,8 @@ SIGNATURES = {
     "ec_expr_source": (I32, [C.POINTER(C.c_uint8), I32, I32, C.POINTER(EcExprStep), I32, C.c_char_p, C.c_char_p, SZ, C.POINTER(SZ)]),
     "ec_host_alloc": (I32, [PVP, SZ]),
     "ec_host_free": (I32, [VP]),
+    "ec_host_masked_expr": (I32, [C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(PV), I32, PV, I32, C.POINTER(EcExprStep), I32, SZ, VP,
+                                  C.POINTER(C.c_double), VP, SZ]),
     "ec_host_expr": (I32, [C.POINTER(C.c_uint8), C.POINTER(VP), I32, PV, I32, C.POINTER(EcExprStep), I32, SZ, VP, SZ]),
     "ec_masked_expr": (I32, [C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(VP), I32, PV, I32, C.POINTER(EcExprStep), I32, SZ, VP, U8P, VP]),
     "ec_neg": (I32, [C.c_uint8, VP, SZ, VP, VP]),

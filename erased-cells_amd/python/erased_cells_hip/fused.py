@@ -129,6 +129,32 @@ def program_host(arrays, scalars, steps, out=None, chunk_cells: int = 0):
     return out[:n]
 
 
+def program_host_masked(arrays, nodata, scalars, steps, out_nodata=None, out=None, want_mask=False, chunk_cells: int = 0):
+    """The masked form of `program_host` (`ec_host_masked_expr`): `nodata[k]` is stream k's nodata value (None: the stream has
+    none) — the masks are derived, ANDed and applied on the device while the chunks stream through.  Returns the f64 result with
+    `out_nodata` in the cells that are not valid (None: the values of all cells), and the result's mask too with `want_mask`."""
+    import numpy as np
+    from ._ffi import EcExprStep, EcValue
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    n = min(a.size for a in arrays)
+    k = len(arrays)
+    cts = [B.cell_type_of(a.dtype) for a in arrays]
+    dt = (C.c_uint8 * k)(*cts)
+    p = (C.c_void_p * k)(*[a.ctypes.data for a in arrays])
+    nds = [None if v is None else B.CellValue(ct, v).to_ec() for ct, v in zip(cts, nodata)]
+    nd = (C.POINTER(EcValue) * k)(*[C.pointer(v) if v is not None else C.POINTER(EcValue)() for v in nds])
+    sc = (EcValue * max(1, len(scalars)))(*[B.CellValue.new(x).to_ec() for x in scalars])
+    st = (EcExprStep * len(steps))(*[EcExprStep(*s_) for s_ in steps])
+    if out is None:
+        out = np.empty(n, dtype=np.float64)
+    assert out.dtype == np.float64 and out.flags.c_contiguous and out.size >= n
+    mask = np.empty(n, dtype=np.uint8) if want_mask else None
+    ond = C.c_double(out_nodata) if out_nodata is not None else None
+    check(lib().ec_host_masked_expr(dt, p, nd, k, sc, len(scalars), st, len(steps), n, out.ctypes.data, C.byref(ond) if ond is not None else None,
+                                    mask.ctypes.data if mask is not None else None, chunk_cells))
+    return (out[:n], mask.astype(bool)) if want_mask else out[:n]
+
+
 def program_source(cell_types, n_scalars, steps, arch=None) -> str:
     """The HIP source the library compiles for a program when it compiles it for itself (`ec_expr_source`; no GPU needed).
     With `arch` (e.g. "gfx950") the source is also compiled once with hiprtc; a failure raises with the compiler's log."""

@@ -149,6 +149,9 @@ extern "C" {
     pub fn ec_host_free(hptr: *mut c_void) -> ec_status;
     pub fn ec_host_expr(dt: *const ec_dtype, p_host: *const *const c_void, n_streams: i32, scalars: *const ec_value, n_scalars: i32,
                         steps: *const ec_expr_step, n_steps: i32, n: usize, out_host: *mut f64, chunk_cells: usize) -> ec_status;
+    pub fn ec_host_masked_expr(dt: *const ec_dtype, p_host: *const *const c_void, nodata: *const *const ec_value, n_streams: i32,
+                               scalars: *const ec_value, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32, n: usize,
+                               out_host: *mut f64, out_nodata_or_null: *const f64, out_mask_host_or_null: *mut u8, chunk_cells: usize) -> ec_status;
     pub fn ec_comm_get_unique_id(uid: *mut ec_comm_uid) -> ec_status;
     pub fn ec_comm_init_rank(uid: *const ec_comm_uid, n_ranks: i32, rank: i32, comm: *mut ec_comm) -> ec_status;
     pub fn ec_comm_init_all(devices: *const i32, n: i32, comms: *mut ec_comm) -> ec_status;

@@ -251,6 +251,15 @@ ec_status ec_host_free(void *hptr);
 ec_status ec_host_expr(const ec_dtype *dt, const void *const *p_host, int32_t n_streams, const ec_value *scalars,
                        int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps, size_t n, double *out_host,
                        size_t chunk_cells);
+/* The masked form, host to host: MaskedCellBuffer::from_vec_with_nodata (src/masked/masked_buffer.rs:62-71) of every
+ * stream — nodata[k] typed as dt[k], or NULL for NoData::None — the program with the AND of the masks (:326-364), and
+ * to_vec_with_nodata (:137-152) of the f64 result: out_host[i] = valid ? value : *out_nodata_or_null (NULL: the values of
+ * all cells, as the reference computes them); out_mask_host_or_null receives the result's mask (1 = valid).  The masks
+ * are derived and applied on the device: what crosses the link is still the operands up and 8 (+ 1) bytes per cell down. */
+ec_status ec_host_masked_expr(const ec_dtype *dt, const void *const *p_host, const ec_value *const *nodata,
+                              int32_t n_streams, const ec_value *scalars, int32_t n_scalars,
+                              const ec_expr_step *steps, int32_t n_steps, size_t n, double *out_host,
+                              const double *out_nodata_or_null, uint8_t *out_mask_host_or_null, size_t chunk_cells);
 
 /* ---------------------------------------------------------------- *
  * min/max under the reference's total order (ints natural; floats total_cmp),

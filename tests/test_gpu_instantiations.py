@@ -748,6 +748,40 @@ def test_host_to_host_expression_pipeline(ec):
         P.program_host(hs, [2.5], [(eco.ADD, S(0), R(1), 0)])  # register read before it is written
 
 
+def test_host_to_host_masked_expression_pipeline(ec):
+    """`ec_host_masked_expr`: from_vec_with_nodata of every stream, the program with the AND of the masks, to_vec_with_nodata of
+    the f64 result — in one streamed call.  Streams with and without a nodata value, integer and float nodata, ragged chunks;
+    values and mask against the oracle."""
+    P = ec.fused
+    n = 300001
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 2000, n).astype(np.uint16)
+    b = rng.uniform(-50, 50, n).astype(np.float32)
+    c = rng.integers(-100, 100, n).astype(np.int8)
+    a[rng.integers(0, n, 5000)] = 0              # nodata 0 in the u16 band
+    b[rng.integers(0, n, 7000)] = np.float32(-9999.0)
+    S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+    steps = [(eco.SUB, S(0), S(1), 0), (eco.MUL, S(2), K(0), 1), (eco.DIV, R(0), R(1), 2), (eco.ADD, R(2), S(0), 0)]
+    vals, loose = _oracle_program([a, b, c], [0.5], steps)
+    valid = (a != 0) & (b != np.float32(-9999.0))   # the i8 stream has no nodata value: all valid
+    for chunk in (0, 65536, 77777):
+        out, mask = P.program_host_masked([a, b, c], [0, -9999.0, None], [0.5], steps, out_nodata=-1e30, want_mask=True, chunk_cells=chunk)
+        assert np.array_equal(mask, valid)
+        assert_f64_bits_equal(out, np.where(valid, vals, -1e30), nan_by_class_where=loose & valid)
+    # without an output nodata value the values of ALL cells come back, as the reference computes them (masked_buffer.rs:326-335)
+    out = P.program_host_masked([a, b, c], [0, -9999.0, None], [0.5], steps)
+    assert_f64_bits_equal(out, vals, nan_by_class_where=loose)
+    # the device-resident masked path says the same
+    ma = ec.MaskedCellBuffer.from_vec_with_nodata(a, ec.NoData.new(np.uint16(0)))
+    mb = ec.MaskedCellBuffer.from_vec_with_nodata(b, ec.NoData.new(np.float32(-9999.0)))
+    mc = ec.MaskedCellBuffer.from_vec(c)
+    res = P.program([ma, mb, mc], [0.5], steps)
+    assert np.array_equal(res.mask().to_numpy().astype(bool), valid)
+    assert np.array_equal(bits_of(res.buffer().to_numpy()), bits_of(out))
+    with pytest.raises(Exception):
+        P.program_host_masked([a, b], [0, None], [], [(eco.ADD, S(0), R(0), 0)])  # malformed program: refused before any transfer
+
+
 def test_expr_rejects_malformed_programs(ec, pool):
     host, dev, _, _ = pool
     L, E = ec.lib(), ec._ffi
