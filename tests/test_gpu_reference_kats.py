@@ -446,6 +446,23 @@ def test_raster_ingest_mirror(ec, golden_dir):
         raster.nodata_from_f64(ec.Int16, float("nan"))
 
 
+def test_ndvi_host_to_host_on_the_fixtures(ec, golden_dir):
+    """The reference's two GDAL tests (src/gdal/rasterband.rs:138-191) with nothing resident on the GPU: the bands stay numpy
+    arrays, NDVI is one streamed call (`ec_host_expr` / `ec_host_masked_expr`, 2000-cell chunks), the answers are the
+    reference's (B.25-B.27)."""
+    P = ec.fused
+    red_c, red_nd = _band(golden_dir, "B4")
+    nir_c, _ = _band(golden_dir, "B5")
+    nd_c, nir_nd = _band(golden_dir, "B5-nd")
+    S, R = (lambda k: k), (lambda k: 4 + k)
+    ndvi = [(ec.SUB, S(0), S(1), 0), (ec.ADD, S(0), S(1), 1), (ec.DIV, R(0), R(1), 0)]
+    out = P.program_host([nir_c.ravel(), red_c.ravel()], [], ndvi, chunk_cells=2000)
+    assert float(out.min()).hex() == NDVI_MIN_HEX and float(out.max()).hex() == NDVI_MAX_HEX
+    out, valid = P.program_host_masked([nd_c.ravel(), red_c.ravel()], [nir_nd, red_nd], [], ndvi, out_nodata=-9999.0, want_mask=True, chunk_cells=2000)
+    assert (int(valid.sum()), int((~valid).sum())) == (31430, 4) and np.all(out[~valid] == -9999.0)
+    assert float(out[valid].min()).hex() == NDVI_MIN_HEX and float(out[valid].max()).hex() == NDVI_MAX_HEX
+
+
 def test_ndvi_fused_single_pass(ec, golden_dir):
     """The same two GDAL tests through the fused single-pass kernel: identical bits."""
     red_c, red_nd = _band(golden_dir, "B4")
