@@ -614,6 +614,36 @@ extern "C" ec_status ec_sharded_expr(ec_shard_group* g, const ec_dtype* dt, cons
     });
 }
 
+// Host memory in, host memory out over ALL the GPUs of the group: the raster's row-blocks (ec_shard_range) go through
+// ec_host_expr / ec_host_masked_expr side by side, one pipeline per launch thread — every GPU has its own PCIe link, so a
+// host-resident raster is bound by the sum of the links (and then by host memory), not by one of them.  Synchronous.
+extern "C" ec_status ec_sharded_host_expr(ec_shard_group* g, const ec_dtype* dt, const void* const* p_host, const ec_value* const* nodata_or_null,
+                                          int32_t n_streams, const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps,
+                                          uint64_t n_rows, uint64_t n_cols, double* out_host, const double* out_nodata_or_null,
+                                          uint8_t* out_mask_host_or_null, size_t chunk_cells) {
+    ec_status st = check_group(g, "ec_sharded_host_expr");
+    if (st != EC_OK) return st;
+    if (!dt || !p_host || !steps || !out_host) return set_error(EC_ERR_ARG, "ec_sharded_host_expr: null argument");
+    {   // the program, once, on the calling thread
+        size_t len = 0;
+        if ((st = ec_expr_source(dt, n_streams, n_scalars, steps, n_steps, nullptr, nullptr, 0, &len)) != EC_OK) return st;
+    }
+    for (int k = 0; k < n_streams; ++k)
+        if (!p_host[k]) return set_error(EC_ERR_ARG, "ec_sharded_host_expr: stream %d is null", k);
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    return for_each_shard(g, [&](int i) {
+        uint64_t off = 0, len = 0;
+        ec_status s = ec_shard_range(n_rows, n_cols, static_cast<uint32_t>(i), static_cast<uint32_t>(g->n), &off, &len);
+        if (s != EC_OK || len == 0) return s;
+        const void* p[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < n_streams; ++k) p[k] = static_cast<const char*>(p_host[k]) + off * ecl::size_of(dt[k]);
+        if (nodata_or_null)
+            return ec_host_masked_expr(dt, p, nodata_or_null, n_streams, scalars, n_scalars, steps, n_steps, len, out_host + off, out_nodata_or_null,
+                                       out_mask_host_or_null ? out_mask_host_or_null + off : nullptr, chunk_cells);
+        return ec_host_expr(dt, p, n_streams, scalars, n_scalars, steps, n_steps, len, out_host + off, chunk_cells);
+    });
+}
+
 // ---- reductions: synchronous, phased (see the head of this file)
 extern "C" ec_status ec_sharded_min_max(ec_shard_group* g, ec_dtype t, const void* const* p, const uint8_t* const* masks_or_null,
                                         const size_t* n, ec_value* mn, ec_value* mx) {

@@ -122,6 +122,8 @@ SIGNATURES = {
     "ec_sharded_masked_binop": (I32, [VP, I32, C.c_uint8, PVP, PVP, C.c_uint8, PVP, PVP, PSZ, PVP, PVP]),
     "ec_sharded_convert": (I32, [VP, C.c_uint8, PVP, C.c_uint8, PVP, PSZ]),
     "ec_sharded_mask_from_nodata": (I32, [VP, C.c_uint8, PVP, PSZ, PV, PVP]),
+    "ec_sharded_host_expr": (I32, [VP, C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(PV), I32, PV, I32, C.POINTER(EcExprStep), I32, C.c_uint64,
+                                   C.c_uint64, VP, C.POINTER(C.c_double), VP, SZ]),
     "ec_sharded_expr": (I32, [VP, C.POINTER(C.c_uint8), C.POINTER(PVP), C.POINTER(PVP), I32, PV, I32, C.POINTER(EcExprStep), I32, PSZ, PVP, PVP]),
     "ec_sharded_fused": (I32, [VP, I32, I32, I32, C.POINTER(C.c_uint8), C.POINTER(PVP), C.POINTER(PVP), PV, PSZ, PVP, PVP]),
     "ec_sharded_min_max": (I32, [VP, C.c_uint8, PVP, PVP, PSZ, PV, PV]),

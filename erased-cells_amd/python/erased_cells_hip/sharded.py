@@ -212,6 +212,31 @@ class ShardGroup:
                                     om.ptrs if om is not None else None))
         return out if om is None else (out, om)
 
+    def program_host(self, arrays, scalars, steps, rows: int, cols: int, nodata=None, out_nodata=None, want_mask=False, chunk_cells: int = 0):
+        """`fused.program_host` / `program_host_masked` over all the GPUs of the group: the row-blocks of the host arrays
+        (rows x cols cells each) stream through their own device's PCIe link side by side (`ec_sharded_host_expr`)."""
+        import numpy as np
+        from ._ffi import EcExprStep
+        arrays = [np.ascontiguousarray(a).reshape(-1) for a in arrays]
+        n = rows * cols
+        assert all(a.size >= n for a in arrays)
+        k = len(arrays)
+        cts = [B.cell_type_of(a.dtype) for a in arrays]
+        dt = (C.c_uint8 * k)(*cts)
+        p = (C.c_void_p * k)(*[a.ctypes.data for a in arrays])
+        nd = None
+        if nodata is not None:
+            nds = [None if v is None else B.CellValue(ct, v).to_ec() for ct, v in zip(cts, nodata)]
+            nd = (C.POINTER(EcValue) * k)(*[C.pointer(v) if v is not None else C.POINTER(EcValue)() for v in nds])
+        sc = (EcValue * max(1, len(scalars)))(*[B.CellValue.new(x).to_ec() for x in scalars])
+        st = (EcExprStep * len(steps))(*[EcExprStep(*q) for q in steps])
+        out = np.empty(n, dtype=np.float64)
+        mask = np.empty(n, dtype=np.uint8) if want_mask else None
+        ond = C.c_double(out_nodata) if out_nodata is not None else None
+        check(lib().ec_sharded_host_expr(self.handle, dt, p, nd, k, sc, len(scalars), st, len(steps), rows, cols, out.ctypes.data,
+                                         C.byref(ond) if ond is not None else None, mask.ctypes.data if mask is not None else None, chunk_cells))
+        return (out, mask.astype(bool)) if want_mask else out
+
     def min_max(self, sb: ShardedBuffer, mask: ShardedBuffer = None):
         mn, mx = EcValue(), EcValue()
         check(lib().ec_sharded_min_max(self.handle, sb.ct, sb.ptrs, mask.ptrs if mask is not None else None,

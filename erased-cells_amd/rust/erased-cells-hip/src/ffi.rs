@@ -189,6 +189,10 @@ extern "C" {
                            masks_or_null: *const *const *const u8, n_streams: i32, scalars: *const ec_value, n_scalars: i32,
                            steps: *const ec_expr_step, n_steps: i32, n: *const usize, out: *const *mut f64,
                            out_mask_or_null: *const *mut u8) -> ec_status;
+    pub fn ec_sharded_host_expr(g: *mut ec_shard_group, dt: *const ec_dtype, p_host: *const *const c_void, nodata_or_null: *const *const ec_value,
+                                n_streams: i32, scalars: *const ec_value, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32,
+                                n_rows: u64, n_cols: u64, out_host: *mut f64, out_nodata_or_null: *const f64,
+                                out_mask_host_or_null: *mut u8, chunk_cells: usize) -> ec_status;
     pub fn ec_sharded_min_max(g: *mut ec_shard_group, t: ec_dtype, p: *const *const c_void,
                               masks_or_null: *const *const u8, n: *const usize, mn: *mut ec_value,
                               mx: *mut ec_value) -> ec_status;

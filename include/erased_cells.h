@@ -370,6 +370,14 @@ ec_status ec_sharded_expr(ec_shard_group *g, const ec_dtype *dt, const void *con
                           const uint8_t *const *const *masks_or_null, int32_t n_streams, const ec_value *scalars,
                           int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps, const size_t *n,
                           double *const *out, uint8_t *const *out_mask_or_null);
+/* Host memory in, host memory out over all the GPUs of the group: the row-blocks of an n_rows x n_cols raster
+ * (ec_shard_range) go through ec_host_expr — or, with nodata_or_null, ec_host_masked_expr — side by side, one pipeline per
+ * device: a host-resident raster is then bound by the sum of the GPUs' PCIe links, not by one.  Synchronous. */
+ec_status ec_sharded_host_expr(ec_shard_group *g, const ec_dtype *dt, const void *const *p_host,
+                               const ec_value *const *nodata_or_null, int32_t n_streams, const ec_value *scalars,
+                               int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps, uint64_t n_rows,
+                               uint64_t n_cols, double *out_host, const double *out_nodata_or_null,
+                               uint8_t *out_mask_host_or_null, size_t chunk_cells);
 /* BufferOps::min_max (src/buffer.rs:169-173; masked: src/masked/masked_buffer.rs:208-217) of the whole raster:
  * ec_min_max_keys per shard, one all-reduce(MAX) of the 16-byte keys, decode.  masks_or_null == NULL: unmasked.
  * Synchronous result. */

@@ -583,3 +583,29 @@ def test_one_process_per_gpu_shape_without_torch(tmp_path):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("rank 0: ")]
     assert lines == ["rank 0: " + _expected(rows, cols, 1)], r.stdout
     assert not (tmp_path / "ec.uid").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [1, 3, 8])
+def test_host_to_host_over_a_shard_group_on_the_fixtures(ec, golden_dir, G):
+    """`ec_sharded_host_expr`: the reference's GDAL NDVI tests (src/gdal/rasterband.rs:138-191) with the bands in host memory
+    and the row-blocks streamed through the group's devices side by side (169 rows over 8 shards: 22, 21 x 7); plain and
+    masked; the reference's known answers (B.25-B.27), and the same cells as the one-pipeline form."""
+    from erased_cells_hip import raster, sharded
+    red_rb = raster.RasterBand.open(os.path.join(golden_dir, "L8-Elkton-VA-B4.tiff"))
+    nir_rb = raster.RasterBand.open(os.path.join(golden_dir, "L8-Elkton-VA-B5-nd.tiff"))
+    cols, rows = red_rb.size()
+    red_h, nir_h = red_rb.cells.ravel(), nir_rb.cells.ravel()
+    S, R = (lambda k: k), (lambda k: 4 + k)
+    ndvi = [(ec.SUB, S(0), S(1), 0), (ec.ADD, S(0), S(1), 1), (ec.DIV, R(0), R(1), 0)]
+    one = ec.fused.program_host_masked([nir_h, red_h], [0, 0], [], ndvi, out_nodata=-9999.0, want_mask=True)
+    with sharded.ShardGroup([0] * G, host_combine=G > 1) as g:
+        out, valid = g.program_host([nir_h, red_h], [], ndvi, rows, cols, nodata=[0, 0], out_nodata=-9999.0, want_mask=True, chunk_cells=1500)
+        assert (int(valid.sum()), int((~valid).sum())) == (31430, 4)
+        assert np.array_equal(out.view(np.uint64), one[0].view(np.uint64)) and np.array_equal(valid, one[1])
+        assert float(out[valid].min()).hex() == "-0x1.ff8ca5bcc77dcp-4" and float(out[valid].max()).hex() == "0x1.5708125b0ed28p-1"
+        plain = g.program_host([nir_h, red_h], [], ndvi, rows, cols)
+        assert np.array_equal(plain.view(np.uint64), ec.fused.program_host([nir_h, red_h], [], ndvi).view(np.uint64))
+        bad = [(ec.ADD, S(0), R(3), 0)]
+        with pytest.raises(Exception):
+            g.program_host([nir_h, red_h], [], bad, rows, cols)
