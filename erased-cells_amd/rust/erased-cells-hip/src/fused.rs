@@ -176,3 +176,69 @@ pub fn program_masked(streams: &[&MaskedCellBuffer], scalars: &[CellValue], step
     );
     MaskedCellBuffer::new(out, om)
 }
+
+/// A host slice of any cell type as an operand of [`program_host`].
+pub struct HostCells<'a> {
+    ct: CellType,
+    ptr: *const c_void,
+    len: usize,
+    nodata: Option<CellValue>,
+    _borrow: std::marker::PhantomData<&'a ()>,
+}
+
+impl<'a> HostCells<'a> {
+    pub fn new<T: crate::CellEncoding>(data: &'a [T]) -> Self {
+        HostCells { ct: T::cell_type(), ptr: data.as_ptr() as *const c_void, len: data.len(), nodata: None, _borrow: std::marker::PhantomData }
+    }
+    /// The same with a nodata value (`from_vec_with_nodata`): cells equal to it are not valid.
+    pub fn with_nodata<T: crate::CellEncoding>(data: &'a [T], nodata: T) -> Self {
+        let mut s = Self::new(data);
+        s.nodata = Some(CellValue::new(nodata));
+        s
+    }
+}
+
+/// Host memory in, host memory out (`ec_host_expr`): the program over host slices, streamed through the GPU in chunks with
+/// upload, kernel and download overlapped — what the reference's `Vec`-in / `Vec`-out operators cost when nothing stays
+/// resident (PCIe-bound: ≈ 6 Gcells/s at 16384², against ≈ 1.2 for `from_vec` + operator + `to_vec`).
+pub fn program_host(streams: &[HostCells], scalars: &[CellValue], steps: &[Step]) -> Vec<f64> {
+    assert!(!streams.is_empty() && streams.len() <= EC_EXPR_MAX_STREAMS, "1..=4 operands");
+    let n = streams.iter().map(|s| s.len).min().unwrap_or(0);
+    let dt: Vec<u8> = streams.iter().map(|s| s.ct as u8).collect();
+    let p: Vec<*const c_void> = streams.iter().map(|s| s.ptr).collect();
+    let sc: Vec<ec_value> = scalars.iter().map(|v| v.to_ffi()).collect();
+    let mut out = vec![0f64; n];
+    must(
+        unsafe {
+            ec_host_expr(dt.as_ptr(), p.as_ptr(), streams.len() as i32, sc.as_ptr(), sc.len() as i32, steps.as_ptr(), steps.len() as i32, n,
+                         out.as_mut_ptr(), 0)
+        },
+        "ec_host_expr",
+    );
+    out
+}
+
+/// The masked form (`ec_host_masked_expr`): `from_vec_with_nodata` of every operand made with [`HostCells::with_nodata`], the
+/// program with the AND of the masks, `to_vec_with_nodata(out_nodata)` of the f64 result — in one streamed call.  Returns the
+/// values and the validity of every cell.
+pub fn program_host_masked(streams: &[HostCells], scalars: &[CellValue], steps: &[Step], out_nodata: Option<f64>) -> (Vec<f64>, Vec<bool>) {
+    assert!(!streams.is_empty() && streams.len() <= EC_EXPR_MAX_STREAMS, "1..=4 operands");
+    let n = streams.iter().map(|s| s.len).min().unwrap_or(0);
+    let dt: Vec<u8> = streams.iter().map(|s| s.ct as u8).collect();
+    let p: Vec<*const c_void> = streams.iter().map(|s| s.ptr).collect();
+    let nd_values: Vec<Option<ec_value>> = streams.iter().map(|s| s.nodata.map(|v| v.to_ffi())).collect();
+    let nd: Vec<*const ec_value> = nd_values.iter().map(|v| v.as_ref().map_or(std::ptr::null(), |x| x as *const ec_value)).collect();
+    let sc: Vec<ec_value> = scalars.iter().map(|v| v.to_ffi()).collect();
+    let mut out = vec![0f64; n];
+    let mut mask = vec![0u8; n];
+    let ond = out_nodata.unwrap_or(0.0);
+    must(
+        unsafe {
+            ec_host_masked_expr(dt.as_ptr(), p.as_ptr(), nd.as_ptr(), streams.len() as i32, sc.as_ptr(), sc.len() as i32, steps.as_ptr(),
+                                steps.len() as i32, n, out.as_mut_ptr(), if out_nodata.is_some() { &ond } else { std::ptr::null() },
+                                mask.as_mut_ptr(), 0)
+        },
+        "ec_host_masked_expr",
+    );
+    (out, mask.into_iter().map(|b| b != 0).collect())
+}
