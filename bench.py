@@ -121,59 +121,38 @@ def cpu_baseline(side: int, target_s: float) -> dict:
 
 
 def e2e_pipelined(torch, ec, L, a, b, out, n: int, chunk: int = 1 << 25) -> dict:
-    """Host-resident operands -> divide -> host-resident result with copies and compute overlapped: page-locked
-    host buffers, chunks of 2^25 cells, double-buffered device staging, one HIP stream each for H2D, the kernel
-    and D2H, ordered by events.  Never `value`: this is what PCIe allows when the data must start and end on the
-    host (8 B/cell come back), next to the naive pageable from_vec/to_vec path."""
+    """Host-resident operands -> divide -> host-resident result through the library's host-to-host pipeline
+    (`ec_host_expr`, csrc/ec_hostpipe.hip): page-locked host buffers, chunks of 2^25 cells, double-buffered device staging,
+    one HIP stream each for H2D, the kernel and D2H, ordered by events.  Never `value`: this is what PCIe allows when the
+    data must start and end on the host (8 B/cell come back), next to the naive pageable from_vec/to_vec path."""
     import numpy as np
     chk = ec._ffi.check
-    ha = torch.empty(n, dtype=torch.uint8).pin_memory()
-    hb = torch.empty(n, dtype=torch.uint16).pin_memory()
-    ho = torch.empty(n, dtype=torch.float64).pin_memory()
-    # the benchmark's own inputs, copied to the pinned host buffers once (untimed)
-    chk(L.ec_download(C.c_void_p(ha.data_ptr()), a.mem.ptr, n, None))
-    chk(L.ec_download(C.c_void_p(hb.data_ptr()), b.mem.ptr, 2 * n, None))
-    s_in, s_cmp, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
-    chk(L.ec_prepare_stream(s_cmp.cuda_stream))
-    da = [torch.empty(chunk, dtype=torch.uint8, device="cuda") for _ in range(2)]
-    db = [torch.empty(chunk, dtype=torch.uint16, device="cuda") for _ in range(2)]
-    do = [torch.empty(chunk, dtype=torch.float64, device="cuda") for _ in range(2)]
-    ev_in = [torch.cuda.Event() for _ in range(2)]
-    ev_cmp = [torch.cuda.Event() for _ in range(2)]
-    ev_out = [torch.cuda.Event() for _ in range(2)]
-    nchunks = (n + chunk - 1) // chunk
+    P = ec.fused
+    ha, hb, ho = P.pinned_empty(n, np.uint8), P.pinned_empty(n, np.uint16), P.pinned_empty(n, np.float64)
+    # the benchmark's own inputs, copied to the page-locked host buffers once (untimed)
+    chk(L.ec_download(C.c_void_p(ha.ctypes.data), a.mem.ptr, n, None))
+    chk(L.ec_download(C.c_void_p(hb.ctypes.data), b.mem.ptr, 2 * n, None))
+    prog = [(ec.DIV, 0, 1, 0)]  # a single operator is a one-step program
 
     def run():
-        for c in range(nchunks):
-            k, lo = c & 1, c * chunk
-            m = min(chunk, n - lo)
-            with torch.cuda.stream(s_in):
-                s_in.wait_event(ev_cmp[k])  # the kernel that last read this staging pair has finished
-                da[k][:m].copy_(ha[lo:lo + m], non_blocking=True)
-                db[k][:m].copy_(hb[lo:lo + m], non_blocking=True)
-                ev_in[k].record(s_in)
-            s_cmp.wait_event(ev_in[k])
-            s_cmp.wait_event(ev_out[k])  # the previous result in this staging buffer has left for the host
-            chk(L.ec_binop(ec.DIV, ec.UInt8, da[k].data_ptr(), ec.UInt16, db[k].data_ptr(), m, do[k].data_ptr(), s_cmp.cuda_stream))
-            ev_cmp[k].record(s_cmp)
-            with torch.cuda.stream(s_out):
-                s_out.wait_event(ev_cmp[k])
-                ho[lo:lo + m].copy_(do[k][:m], non_blocking=True)
-                ev_out[k].record(s_out)
-        torch.cuda.synchronize()
+        P.program_host([ha, hb], [], prog, out=ho, chunk_cells=chunk)
 
-    run()  # warm (page tables of the pinned buffers, streams)
-    t = time.perf_counter()
-    run()
-    dt = time.perf_counter() - t
+    run()  # warm (page tables of the pinned buffers, the pool's staging blocks)
+    best = None
+    for _ in range(3):
+        t = time.perf_counter()
+        run()
+        dt = time.perf_counter() - t
+        best = dt if best is None or dt < best else best
+    dt = best
+    nchunks = (n + chunk - 1) // chunk
     # the pipelined result is the resident result: compare two chunks bit for bit
     ref = out.to_numpy()
-    got = ho.numpy()
     for lo in (0, (nchunks - 1) * chunk):
         hi = min(n, lo + chunk)
-        assert np.array_equal(got[lo:hi].view(np.uint64), ref[lo:hi].view(np.uint64)), "pipelined result differs"
+        assert np.array_equal(ho[lo:hi].view(np.uint64), ref[lo:hi].view(np.uint64)), "pipelined result differs"
     return {"value": n / dt / 1e9, "unit": "Gcells/s", "seconds": dt, "host_GBps": 11 * n / dt / 1e9,
-            "what": f"pinned host buffers, {nchunks} chunks of 2^25 cells, H2D / divide / D2H on three streams, double-buffered"}
+            "what": f"ec_host_expr: page-locked host buffers, {nchunks} chunks of 2^25 cells, H2D / divide / D2H on three streams, double-buffered"}
 
 
 def recorded_traffic(key: str, cells_per_launch: int):
