@@ -13,8 +13,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <map>
+#include <mutex>
 #include <vector>
 
+#include "ec_hostpipe.hpp"
 #include "ec_lattice.hpp"
 #include "ec_runtime.hpp"
 #include "erased_cells.h"
@@ -27,32 +31,66 @@ extern "C" ec_status ec_host_alloc(void** hptr, size_t bytes) {
     if (st != EC_OK) return st;
     *hptr = nullptr;
     if (bytes == 0) return EC_OK;
-    return check_hip(hipHostMalloc(hptr, bytes, hipHostMallocDefault), "hipHostMalloc");
+    return check_hip(hipHostMalloc(hptr, bytes, hipHostMallocPortable), "hipHostMalloc");  // page-locked for every device
 }
 
 extern "C" ec_status ec_host_free(void* hptr) { return hptr ? check_hip(hipHostFree(hptr), "hipHostFree") : EC_OK; }
 
 namespace {
+struct PinTable {
+    struct Entry { size_t bytes; int refs; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::map<uintptr_t, Entry> live;  // registrations made here, by base address
+} g_pins;
+}  // namespace
 
-// Registers a host range for the life of the object unless it already is page-locked.
-struct Pinned {
-    void* p = nullptr;
-    bool ours = false;
-    void pin(const void* ptr, size_t bytes) {
-        hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeHost) return;  // already page-locked
-        (void)hipGetLastError();  // "not a HIP pointer" is an answer, not a failure
-        if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) {
-            p = const_cast<void*>(ptr);
-            ours = true;
-        } else {
-            (void)hipGetLastError();  // refused (e.g. a read-only mapping): the runtime's pageable path will do
+namespace ecd {
+
+void Pinned::pin(const void* ptr, size_t bytes) {
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes;
+    std::unique_lock<std::mutex> lk(g_pins.mu);
+    for (;;) {
+        bool wait = false;
+        for (auto& kv : g_pins.live) {
+            const uintptr_t elo = kv.first, ehi = kv.first + kv.second.bytes;
+            if (ehi <= lo || hi <= elo) continue;
+            if (elo <= lo && hi <= ehi) {  // covered by a registration in flight: share it
+                ++kv.second.refs;
+                base = elo;
+                return;
+            }
+            wait = true;
+            break;
         }
+        if (!wait) break;
+        g_pins.cv.wait(lk);
     }
-    ~Pinned() {
-        if (ours) (void)hipHostUnregister(p);
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeHost) return;  // page-locked by the caller
+    (void)hipGetLastError();  // "not a HIP pointer" is an answer, not a failure
+    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable)  /* page-locked for every device: a shard group copies from it on all of them */ == hipSuccess) {
+        g_pins.live[lo] = PinTable::Entry{bytes, 1};
+        base = lo;
+    } else {
+        (void)hipGetLastError();  // refused (e.g. a read-only mapping): the runtime's pageable path will do
     }
-};
+}
+
+Pinned::~Pinned() {
+    if (!base) return;
+    std::lock_guard<std::mutex> lk(g_pins.mu);
+    auto it = g_pins.live.find(base);
+    if (it != g_pins.live.end() && --it->second.refs == 0) {
+        (void)hipHostUnregister(reinterpret_cast<void*>(base));
+        g_pins.live.erase(it);
+        g_pins.cv.notify_all();
+    }
+}
+
+}  // namespace ecd
+
+namespace {
 
 struct Pipe {
     hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;

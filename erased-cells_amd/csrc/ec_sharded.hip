@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "ec_collective.hpp"
+#include "ec_hostpipe.hpp"
 #include "ec_lattice.hpp"
 #include "ec_runtime.hpp"
 
@@ -630,6 +631,15 @@ extern "C" ec_status ec_sharded_host_expr(ec_shard_group* g, const ec_dtype* dt,
     }
     for (int k = 0; k < n_streams; ++k)
         if (!p_host[k]) return set_error(EC_ERR_ARG, "ec_sharded_host_expr: stream %d is null", k);
+    // the WHOLE arrays are page-locked once, here; the shards' pipelines find their row-blocks inside these registrations
+    // (row-blocks end in the middle of pages: registering them one by one would collide on the shared pages)
+    const uint64_t n = n_rows * n_cols;
+    Pinned whole[6];
+    if (ensure_ready() == EC_OK) {
+        for (int k = 0; k < n_streams; ++k) whole[k].pin(p_host[k], n * ecl::size_of(dt[k]));
+        whole[4].pin(out_host, n * sizeof(double));
+        if (out_mask_host_or_null) whole[5].pin(out_mask_host_or_null, n);
+    }
     std::lock_guard<std::mutex> lk(g->call_mu);
     return for_each_shard(g, [&](int i) {
         uint64_t off = 0, len = 0;

@@ -741,6 +741,24 @@ def test_host_to_host_expression_pipeline(ec):
     got = P.program_host(pinned, [2.5], steps, out=out, chunk_cells=1 << 18)
     assert got.ctypes.data == out.ctypes.data
     assert_f64_bits_equal(out, exp, nan_by_class_where=loose)
+    # four host threads, each its own pipeline (own streams, own staging from the shared pool), at once
+    import threading
+    results, errors = [None] * 4, []
+
+    def worker(k):
+        try:
+            results[k] = P.program_host(hs, [2.5], steps, chunk_cells=50000 + 1111 * k)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for r in results:
+        assert_f64_bits_equal(r, exp, nan_by_class_where=loose)
     # a single operator is a one-step program: the reference's quick example, host to host
     q = P.program_host([np.array([1, 2, 3], np.uint8), np.array([2, 4, 6], np.uint16)], [0.5], [(eco.DIV, S(0), S(1), 0), (eco.MUL, R(0), K(0), 0)])
     assert q.tolist() == [0.25, 0.25, 0.25]
