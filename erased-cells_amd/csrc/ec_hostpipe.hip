@@ -41,51 +41,74 @@ struct PinTable {
     struct Entry { size_t bytes; int refs; };
     std::mutex mu;
     std::condition_variable cv;
-    std::map<uintptr_t, Entry> live;  // registrations made here, by base address
+    std::map<uintptr_t, Entry> live;  // registrations made here, by (page-aligned) base address
 } g_pins;
+constexpr uintptr_t kPage = 4096;
 }  // namespace
 
 namespace ecd {
 
-void Pinned::pin(const void* ptr, size_t bytes) {
-    const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes;
+void PinSet::pin_all(const std::vector<std::pair<const void*, size_t>>& ranges) {
+    // whole pages, merged
+    std::vector<std::pair<uintptr_t, uintptr_t>> iv;
+    for (const auto& r : ranges) {
+        if (!r.first || r.second == 0) continue;
+        const uintptr_t lo = reinterpret_cast<uintptr_t>(r.first) / kPage * kPage;
+        const uintptr_t hi = (reinterpret_cast<uintptr_t>(r.first) + r.second + kPage - 1) / kPage * kPage;
+        iv.emplace_back(lo, hi);
+    }
+    std::sort(iv.begin(), iv.end());
+    std::vector<std::pair<uintptr_t, uintptr_t>> merged;
+    for (const auto& x : iv) {
+        if (!merged.empty() && x.first <= merged.back().second) merged.back().second = std::max(merged.back().second, x.second);
+        else merged.push_back(x);
+    }
     std::unique_lock<std::mutex> lk(g_pins.mu);
-    for (;;) {
-        bool wait = false;
-        for (auto& kv : g_pins.live) {
-            const uintptr_t elo = kv.first, ehi = kv.first + kv.second.bytes;
-            if (ehi <= lo || hi <= elo) continue;
-            if (elo <= lo && hi <= ehi) {  // covered by a registration in flight: share it
-                ++kv.second.refs;
-                base = elo;
-                return;
+    for (;;) {  // wait (holding nothing) while a range partly overlaps a registration of another call in flight
+        bool conflict = false;
+        for (const auto& m : merged)
+            for (const auto& kv : g_pins.live) {
+                const uintptr_t elo = kv.first, ehi = kv.first + kv.second.bytes;
+                if (ehi <= m.first || m.second <= elo) continue;
+                if (!(elo <= m.first && m.second <= ehi)) conflict = true;
             }
-            wait = true;
-            break;
-        }
-        if (!wait) break;
+        if (!conflict) break;
         g_pins.cv.wait(lk);
     }
-    hipPointerAttribute_t at{};
-    if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeHost) return;  // page-locked by the caller
-    (void)hipGetLastError();  // "not a HIP pointer" is an answer, not a failure
-    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterPortable)  /* page-locked for every device: a shard group copies from it on all of them */ == hipSuccess) {
-        g_pins.live[lo] = PinTable::Entry{bytes, 1};
-        base = lo;
-    } else {
-        (void)hipGetLastError();  // refused (e.g. a read-only mapping): the runtime's pageable path will do
+    for (const auto& m : merged) {
+        bool shared = false;
+        for (auto& kv : g_pins.live)
+            if (kv.first <= m.first && m.second <= kv.first + kv.second.bytes) {  // inside a registration in flight: share it
+                ++kv.second.refs;
+                held_.push_back(kv.first);
+                shared = true;
+                break;
+            }
+        if (shared) continue;
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, reinterpret_cast<const void*>(m.first)) == hipSuccess && at.type == hipMemoryTypeHost) continue;  // the caller's own page-locked memory
+        (void)hipGetLastError();  // "not a HIP pointer" is an answer, not a failure
+        // page-locked for every device: a shard group copies from it on all of them
+        if (hipHostRegister(reinterpret_cast<void*>(m.first), m.second - m.first, hipHostRegisterPortable) == hipSuccess) {
+            g_pins.live[m.first] = PinTable::Entry{m.second - m.first, 1};
+            held_.push_back(m.first);
+        } else {
+            (void)hipGetLastError();  // refused (a read-only mapping, ...): the runtime's pageable path copies such a range
+        }
     }
 }
 
-Pinned::~Pinned() {
-    if (!base) return;
+PinSet::~PinSet() {
+    if (held_.empty()) return;
     std::lock_guard<std::mutex> lk(g_pins.mu);
-    auto it = g_pins.live.find(base);
-    if (it != g_pins.live.end() && --it->second.refs == 0) {
-        (void)hipHostUnregister(reinterpret_cast<void*>(base));
-        g_pins.live.erase(it);
-        g_pins.cv.notify_all();
+    for (uintptr_t base : held_) {
+        auto it = g_pins.live.find(base);
+        if (it != g_pins.live.end() && --it->second.refs == 0) {
+            (void)hipHostUnregister(reinterpret_cast<void*>(base));
+            g_pins.live.erase(it);
+        }
     }
+    g_pins.cv.notify_all();
 }
 
 }  // namespace ecd
@@ -176,10 +199,14 @@ static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void*
         off_sel = at;
         at = align_up(at + chunk * sizeof(double), 256);
     }
-    Pinned pins[6];
-    for (int k = 0; k < n_streams; ++k) pins[k].pin(p_host[k], n * bytes_per_cell[k]);
-    pins[4].pin(out_host, n * sizeof(double));
-    if (out_mask_host) pins[5].pin(out_mask_host, n);
+    PinSet pins;
+    {
+        std::vector<std::pair<const void*, size_t>> ranges;
+        for (int k = 0; k < n_streams; ++k) ranges.emplace_back(p_host[k], n * bytes_per_cell[k]);
+        ranges.emplace_back(out_host, n * sizeof(double));
+        if (out_mask_host) ranges.emplace_back(out_mask_host, n);
+        pins.pin_all(ranges);
+    }
     Pipe pipe;
     if ((st = pipe.open(at)) != EC_OK) return st;
     ec_value sel{};

@@ -3,21 +3,29 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <utility>
+#include <vector>
 
 namespace ecd {
 
-// Page-locks a host range for the life of the object unless the caller already did.  Calls that run at the same time may
-// share operands (the same numpy array in two threads; the row-blocks of one raster on the launch threads of a shard
-// group): the registrations the library makes are counted in one table, so that the call that finishes first does not
-// unregister pages another call is still copying from, and a range inside a registration in flight shares it.  A range that
-// only partly overlaps one waits for it (hipHostRegister refuses overlapping ranges).
-struct Pinned {
-    uintptr_t base = 0;  // key of the table entry this object holds a reference on (0: none)
-    void pin(const void* ptr, size_t bytes);
-    ~Pinned();
-    Pinned() = default;
-    Pinned(const Pinned&) = delete;
-    Pinned& operator=(const Pinned&) = delete;
+// Page-locks the host ranges of ONE call for the life of the object, unless the caller already did.
+//
+// hipMemcpyAsync refuses a range that lies only partly inside a registration, and hipHostRegister refuses a range that overlaps
+// one — so the ranges of a call are first widened to whole pages and merged (two windows of one array as two operands, two
+// small arrays on one page), and every registration the library makes is counted in one table: calls that run at the same
+// time may share operands (the same array in two threads; the row-blocks of a raster on the launch threads of a shard group,
+// inside the registration their caller made for the whole raster), and the call that finishes first does not unregister
+// pages another is still copying from.  A range that partly overlaps a registration of ANOTHER call in flight waits for
+// that call — holding nothing while it waits, all of a call's ranges are taken at once.
+class PinSet {
+    std::vector<uintptr_t> held_;  // table keys this object holds a reference on
+
+public:
+    void pin_all(const std::vector<std::pair<const void*, size_t>>& ranges);
+    ~PinSet();
+    PinSet() = default;
+    PinSet(const PinSet&) = delete;
+    PinSet& operator=(const PinSet&) = delete;
 };
 
 }  // namespace ecd

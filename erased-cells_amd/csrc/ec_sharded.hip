@@ -634,11 +634,13 @@ extern "C" ec_status ec_sharded_host_expr(ec_shard_group* g, const ec_dtype* dt,
     // the WHOLE arrays are page-locked once, here; the shards' pipelines find their row-blocks inside these registrations
     // (row-blocks end in the middle of pages: registering them one by one would collide on the shared pages)
     const uint64_t n = n_rows * n_cols;
-    Pinned whole[6];
+    PinSet whole;
     if (ensure_ready() == EC_OK) {
-        for (int k = 0; k < n_streams; ++k) whole[k].pin(p_host[k], n * ecl::size_of(dt[k]));
-        whole[4].pin(out_host, n * sizeof(double));
-        if (out_mask_host_or_null) whole[5].pin(out_mask_host_or_null, n);
+        std::vector<std::pair<const void*, size_t>> ranges;
+        for (int k = 0; k < n_streams; ++k) ranges.emplace_back(p_host[k], n * ecl::size_of(dt[k]));
+        ranges.emplace_back(out_host, n * sizeof(double));
+        if (out_mask_host_or_null) ranges.emplace_back(out_mask_host_or_null, n);
+        whole.pin_all(ranges);
     }
     std::lock_guard<std::mutex> lk(g->call_mu);
     return for_each_shard(g, [&](int i) {

@@ -759,6 +759,12 @@ def test_host_to_host_expression_pipeline(ec):
     assert not errors, errors
     for r in results:
         assert_f64_bits_equal(r, exp, nan_by_class_where=loose)
+    # two overlapping windows of ONE host array as two operands (registrations may not overlap: the second goes the pageable way)
+    base = rand_cells(eco.U16, 400000, 77)
+    w0, w1 = base[:300000], base[1000:301000]
+    prog = [(eco.SUB, S(0), S(1), 0), (eco.MUL, R(0), K(0), 0)]
+    e2, l2 = _oracle_program([w0, w1], [0.5], prog)
+    assert_f64_bits_equal(P.program_host([w0, w1], [0.5], prog, chunk_cells=65536), e2, nan_by_class_where=l2)
     # a single operator is a one-step program: the reference's quick example, host to host
     q = P.program_host([np.array([1, 2, 3], np.uint8), np.array([2, 4, 6], np.uint16)], [0.5], [(eco.DIV, S(0), S(1), 0), (eco.MUL, R(0), K(0), 0)])
     assert q.tolist() == [0.25, 0.25, 0.25]
