@@ -245,7 +245,9 @@ ec_status ec_expr_source(const ec_dtype *dt, int32_t n_streams, int32_t n_scalar
  * of `chunk_cells` cells (0 = 2^25), upload / kernel / download on three streams over double-buffered device staging,
  * so both directions of the link are busy at once.  Page-locked buffers (ec_host_alloc) are copied asynchronously as
  * they are; any other buffer is page-locked for the duration of the call (hipHostRegister: about one pass over the
- * pages) and, if that is refused, copied through the runtime's pageable path.  Synchronous; uses its own streams. */
+ * pages) and, if that is refused, copied through the runtime's pageable path.  Operands may be windows of one array and
+ * may overlap each other; out_host may be one of the f64 operands itself (same address), not a shifted window of one.
+ * Synchronous; uses its own streams; may be called from several host threads at once. */
 ec_status ec_host_alloc(void **hptr, size_t bytes); /* page-locked host memory */
 ec_status ec_host_free(void *hptr);
 ec_status ec_host_expr(const ec_dtype *dt, const void *const *p_host, int32_t n_streams, const ec_value *scalars,
