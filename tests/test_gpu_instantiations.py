@@ -765,6 +765,11 @@ def test_host_to_host_expression_pipeline(ec):
     prog = [(eco.SUB, S(0), S(1), 0), (eco.MUL, R(0), K(0), 0)]
     e2, l2 = _oracle_program([w0, w1], [0.5], prog)
     assert_f64_bits_equal(P.program_host([w0, w1], [0.5], prog, chunk_cells=65536), e2, nan_by_class_where=l2)
+    # in place: the result array is one of the (f64) operands
+    x = np.linspace(-5.0, 5.0, 200001)
+    want = eco.f_binop(eco.MUL, x, np.full(x.size, 2.5))
+    got = P.program_host([x], [2.5], [(eco.MUL, S(0), K(0), 0)], out=x, chunk_cells=30000)
+    assert got.ctypes.data == x.ctypes.data and np.array_equal(bits_of(x), bits_of(want))
     # a single operator is a one-step program: the reference's quick example, host to host
     q = P.program_host([np.array([1, 2, 3], np.uint8), np.array([2, 4, 6], np.uint16)], [0.5], [(eco.DIV, S(0), S(1), 0), (eco.MUL, R(0), K(0), 0)])
     assert q.tolist() == [0.25, 0.25, 0.25]
