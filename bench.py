@@ -25,6 +25,11 @@ port of the same operation timed on this box's host cores on a bounded sample.
 Other workloads (not bench lines; used for profiles/ and DESIGN.md):
   --workload masked_chain   config 3: f32 (a+b)*c with 30 % nodata masks
   --workload minmax         config 4 per-GPU shard: u16 min_max (+ all-reduce of the keys)
+  --workload ndvi           config 5's arithmetic at raster scale: eager, --fused (one pass), --mixed (u16 + f32 bands)
+  --workload evi            an eight-operator tree over three u16 bands: eager, --fused (ec_expr, the program compiled for
+                            itself), --fused --interpret (the interpreter kernel)
+  --workload binop          any cell-type pair and operator (--lt --rt --op)
+  --e2e                     adds the host-memory-in / host-memory-out legs (naive from_vec/to_vec; ec_host_expr)
 """
 from __future__ import annotations
 
