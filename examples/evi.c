@@ -95,5 +95,31 @@ int main(void) {
     CHECK(ec_free(out));
     for (i = 0; i < 7; ++i) CHECK(ec_free(t[i]));
     CHECK(ec_shutdown());
-    return !(interpreted == 1 && compiled == 1);
+    /* the library again after a shutdown: the compiled program is still cached, its module is loaded anew */
+    CHECK(ec_init(0));
+    CHECK(ec_tune_set("expr_jit", 2));
+    CHECK(ec_alloc(&dn, sizeof nir));
+    CHECK(ec_alloc(&dr, sizeof red));
+    CHECK(ec_alloc(&db, sizeof blue));
+    CHECK(ec_alloc(&out, sizeof got));
+    CHECK(ec_upload(dn, nir, sizeof nir, NULL));
+    CHECK(ec_upload(dr, red, sizeof red, NULL));
+    CHECK(ec_upload(db, blue, sizeof blue, NULL));
+    p[0] = dn;
+    p[1] = dr;
+    p[2] = db;
+    memset(got, 0, sizeof got);
+    CHECK(ec_expr(dt, p, 3, k, 4, prog, 8, N, (double *)out, NULL));
+    CHECK(ec_download(got, out, sizeof got, NULL));
+    CHECK(ec_stat_get("expr_jit_launches", &compiled));
+    if (memcmp(got, want, sizeof got) != 0 || compiled != 2) {
+        fprintf(stderr, "after shutdown + init: result differs or the compiled form did not run (launches %d)\n", (int)compiled);
+        return 3;
+    }
+    CHECK(ec_free(dn));
+    CHECK(ec_free(dr));
+    CHECK(ec_free(db));
+    CHECK(ec_free(out));
+    CHECK(ec_shutdown());
+    return !(interpreted == 1);
 }
