@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -168,8 +169,12 @@ std::once_flag g_rtc_once;
 
 void load_hiprtc() {
     void* h = nullptr;
-    for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6"})
-        if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+    if (const char* named = std::getenv("EC_HIPRTC_LIB")) {  // another ROCm installation's hiprtc, or none at all (tests)
+        h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+    }
     if (!h) {
         const char* e = dlerror();
         g_rtc.load_error = std::string("libhiprtc not found: ") + (e ? e : "dlopen failed");

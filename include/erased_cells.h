@@ -228,7 +228,8 @@ ec_status ec_masked_expr(const ec_dtype *dt, const void *const *p, const uint8_t
  * without it the interpreter keeps serving) — and cache the module per (program, cell types, load policy).  Same cells
  * either way.  ec_tune_set("expr_jit", v): 0 = never compile; 1 (default) = compile on a background thread once a
  * program has interpreted 2^31 cell-steps, launches interpret until the module is ready; 2 = compile on the calling
- * thread at first sight (≈ 0.3 s per program, 3 s for the first) and fail loudly if that fails.  Inside a stream
+ * thread at first sight (≈ 0.3 s per program, 3 s for the first) and fail loudly if that fails.  The environment variable
+ * EC_HIPRTC_LIB names the hiprtc library to load instead of libhiprtc.so.  Inside a stream
  * capture a program whose module is not loaded yet is interpreted.  ec_stat_get: "expr_interp_launches",
  * "expr_jit_launches", "expr_jit_compiles", "expr_jit_failures", "expr_jit_programs".
  *
@@ -242,7 +243,8 @@ ec_status ec_expr_source(const ec_dtype *dt, int32_t n_streams, int32_t n_scalar
  * (src/buffer.rs:12-55, impl $trt for &CellBuffer :324-352); a caller that keeps nothing resident is bound by PCIe —
  * the operands' bytes up, 8 bytes per cell down — not by the kernel.  ec_host_expr evaluates an expression program
  * (ec_expr: a single operator is a one-step program) over HOST arrays p_host[k] of n cells into out_host[0..n): chunks
- * of `chunk_cells` cells (0 = 2^25), upload / kernel / download on three streams over double-buffered device staging,
+ * of `chunk_cells` cells (0 = 2^25), upload / kernel / download on three streams over double-buffered device staging
+ * (two slots of chunk_cells x (the operands' bytes + 8 [+ masks]) from the library's pool: 2 x 370 MB for u8 / u16 at 2^25),
  * so both directions of the link are busy at once.  Page-locked buffers (ec_host_alloc) are copied asynchronously as
  * they are; any other buffer is page-locked for the duration of the call (hipHostRegister: about one pass over the
  * pages) and, if that is refused, copied through the runtime's pageable path.  Operands may be windows of one array and

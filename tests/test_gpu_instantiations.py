@@ -6,6 +6,7 @@ load classes) under every op triple and cell kind, the map kernels at every tile
 executed can be listed with `rocprofv3 --kernel-trace --stats -- python3 -m pytest tests -m gpu`.)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -809,6 +810,45 @@ def test_host_to_host_masked_expression_pipeline(ec):
     assert np.array_equal(bits_of(res.buffer().to_numpy()), bits_of(out))
     with pytest.raises(Exception):
         P.program_host_masked([a, b], [0, None], [], [(eco.ADD, S(0), R(0), 0)])  # malformed program: refused before any transfer
+
+
+def test_expr_without_hiprtc_keeps_interpreting_and_says_so(tmp_path):
+    """A machine without libhiprtc (EC_HIPRTC_LIB pointing nowhere, in a process of its own): `expr_jit` = 1 counts the failed
+    compile and keeps serving the program with the interpreter; `expr_jit` = 2 refuses loudly with the loader's message."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, time, ctypes as C
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import erased_cells_hip as ec
+ec.init(0)
+L, P = ec.lib(), ec.fused
+def stat(k):
+    v = C.c_int64(0); assert L.ec_stat_get(k, C.byref(v)) == 0; return v.value
+n = 1 << 24
+x = ec.CellBuffer.from_vec(np.arange(n, dtype=np.uint16))
+steps = [(ec.MUL, 0, 8, 0)] + [(ec.ADD, 4, 8, 0)] * 15
+for _ in range(9):
+    out = P.program([x], [1.5], steps)
+deadline = time.time() + 30
+while stat(b"expr_jit_failures") == 0 and time.time() < deadline:
+    time.sleep(0.05)
+assert stat(b"expr_jit_failures") == 1 and stat(b"expr_jit_compiles") == 0 and stat(b"expr_jit_launches") == 0
+out = P.program([x], [1.5], steps).to_numpy()
+assert out[3] == 3 * 1.5 + 15 * 1.5 and stat(b"expr_interp_launches") == 10
+L.ec_tune_set(b"expr_jit", 2)
+try:
+    P.program([x], [1.5], [(ec.MUL, 0, 8, 0)])
+    print("NOT REFUSED")
+except Exception as e:
+    print("REFUSED:", e)
+"""
+    env = dict(os.environ, EC_HIPRTC_LIB="/nonexistent/libhiprtc.so")
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "erased-cells_amd", "python")],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "REFUSED:" in r.stdout and "libhiprtc" in r.stdout, r.stdout
 
 
 def test_expr_rejects_malformed_programs(ec, pool):
