@@ -94,6 +94,23 @@ def program(streams, scalars, steps):
     return B.MaskedCellBuffer(out, om)
 
 
+class jit:
+    """`with fused.jit(2): ...` — how expression programs are run inside the block (`ec_tune_set("expr_jit", mode)`): 0 the
+    interpreter kernel only, 1 compiled in the background once a program has run long enough (the default), 2 compiled on the
+    calling thread at first sight.  The previous default (1) is restored on exit."""
+
+    def __init__(self, mode: int):
+        self.mode = mode
+
+    def __enter__(self):
+        check(lib().ec_tune_set(b"expr_jit", self.mode))
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().ec_tune_set(b"expr_jit", 1))
+        return False
+
+
 def pinned_empty(n: int, dtype):
     """A page-locked numpy array (`ec_host_alloc`): what `program_host` copies to and from without registering pages first.
     The memory is returned to the system when the array (and every view of it) is garbage."""
