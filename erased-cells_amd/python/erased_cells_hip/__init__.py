@@ -2,7 +2,10 @@
 
 `_ffi`     ctypes binding of include/erased_cells.h (fails loudly if the .so is missing)
 `buffer`   host mirror of CellBuffer / MaskedCellBuffer / Mask / NoData / CellValue
-`sharded`  row-block sharding across ranks + the RCCL all-reduce for min/max and counts
+`fused`    operator chains and trees in one pass: `expr`, `ndvi`, `lazy()`, expression programs (`program`, interpreted or
+           compiled for themselves), host memory in / host memory out (`program_host`, `program_host_masked`, `pinned_empty`)
+`raster`   baseline-TIFF band reader (the reference's GDAL adaptor for the fixture shape)
+`sharded`  row-block sharding across ranks + the RCCL all-reduce for min/max and counts; `ShardGroup`: one process, all GPUs
 `wire`     serde/JSON shape of the core types (interop only; parity unpinned)
 """
 from . import _ffi, fused, raster, wire

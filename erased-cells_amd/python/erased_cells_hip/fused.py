@@ -1,8 +1,15 @@
-"""Fused operator chains: one pass over HBM for `(x o1 y) o2 (z o3 w)`.
+"""Fused operator chains: one pass over HBM for `(x o1 y) o2 (z o3 w)` — and for operator trees of any depth.
 
 The reference evaluates `(&nir - &red) / (nir + red)` (src/gdal/rasterband.rs:148) or
 `(buf + ones) * 2.0`-style chains eagerly, writing an f64 temporary per operator.  These helpers
 produce bit-identical results (each step is the same rounded f64 op) from a single kernel.
+
+  expr / ndvi / chain3          the two-level shapes (`ec_fused`)
+  program(streams, scalars, steps)   an expression program: ≤ 4 buffers, 8 scalars, 16 steps over 4 registers (`ec_expr`)
+  lazy(buf)                      operator syntax; trees are scheduled onto a program (or the two-level kernel) by `eval()`
+  jit(mode)                      how programs run: interpreted / compiled in the background (default) / compiled at once
+  program_host, program_host_masked, pinned_empty    numpy arrays in, numpy array out, streamed over PCIe (`ec_host_expr`)
+  program_source                 the HIP source the library compiles for a program (no GPU needed)
 """
 from __future__ import annotations
 
