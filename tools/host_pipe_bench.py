@@ -55,6 +55,8 @@ def main():
     row("divide u8/u16, naive: from_vec, operator, to_vec", 11, lambda: (ec.CellBuffer.from_vec(a) / ec.CellBuffer.from_vec(b)).to_numpy())
     row("EVI 3 x u16, page-locked in and out (ec_host_expr)", 14, lambda: P.program_host([pb, pc, pb], ks, evi, out=pout))
     row("EVI 3 x u16, pageable in and out (registered per call)", 14, lambda: P.program_host([b, c, b], ks, evi, out=out))
+    row("EVI 3 x u16 masked (nodata 0 in every band -> mask AND -> nodata in the result), pageable", 14,
+        lambda: P.program_host_masked([b, c, b], [0, 0, 0], ks, evi, out_nodata=-9999.0, out=out))
     for ch in (1 << 22, 1 << 23, 1 << 24, 1 << 26):
         row(f"divide u8/u16, page-locked, chunks of 2^{ch.bit_length() - 1} cells", 11, lambda ch=ch: P.program_host([pa, pb], [], div, out=pout, chunk_cells=ch))
     print(f"| host to host, {side}x{side} cells | link B/cell | seconds | Gcells/s | GB/s over the link (both directions) |")
