@@ -67,15 +67,22 @@ __device__ __forceinline__ double apply_op(double a, double b) {
 template <typename T>
 struct is_small_int { static constexpr bool value = !is_fp<T>::value && sizeof(T) <= 2; };
 
-__device__ __forceinline__ double div_small_int(double a, double b) {
+// the six instructions alone: the quotient for b != 0 (b == 0 gives a NaN here, replaced by the caller)
+__device__ __forceinline__ double div_small_int_nonzero(double a, double b) {
     double y = __builtin_amdgcn_rcp(b);
     const double e = __builtin_fma(-b, y, 1.0);
     y = __builtin_fma(y, e, y);
     double q = a * y;
     const double r = __builtin_fma(-b, q, a);
-    q = __builtin_fma(r, y, q);
-    const double at_zero = a == 0.0 ? bits_f64(kNegQNaN) : (a > 0.0 ? __builtin_inf() : -__builtin_inf());
-    return b == 0.0 ? at_zero : q;
+    return __builtin_fma(r, y, q);
+}
+// what the reference's f64 divide gives for b == 0
+__device__ __forceinline__ double div_by_zero(double a) {
+    return a == 0.0 ? bits_f64(kNegQNaN) : (a > 0.0 ? __builtin_inf() : -__builtin_inf());
+}
+__device__ __forceinline__ double div_small_int(double a, double b) {
+    const double q = div_small_int_nonzero(a, b);
+    return b == 0.0 ? div_by_zero(a) : q;
 }
 
 template <int OP, bool FP_IN, bool SMALL_INT = false>
