@@ -576,6 +576,36 @@ def test_lazy_random_trees_against_the_oracle(ec, pool):
         assert_f64_bits_equal(got.to_numpy(), exp, nan_by_class_where=loose)
     assert seen_programs >= 5, "deep trees over three buffers should have run as single programs"
 
+    # the same with masked buffers: the result's mask is the AND of the masks of the buffers the tree uses
+    _, _, m, dm = pool
+    mbufs = [ec.MaskedCellBuffer(b, dm[k % 2].shard(k, N)) for k, b in enumerate(bufs)]
+    hmask = [m[k % 2][k:k + N].astype(bool) for k in range(len(bufs))]
+
+    def grow_masked(depth, nbuf):
+        if depth == 0 or rng.random() < 0.25:
+            if rng.random() < 0.3:
+                c = float(rng.choice([2.5, -3.0, 0.5, 7.0]))
+                return c, np.full(N, c), np.zeros(N, bool), np.ones(N, bool), False
+            k = int(rng.integers(0, nbuf))
+            return L(mbufs[k]), hs[k], np.zeros(N, bool), hmask[k], True
+        op = int(rng.integers(0, 4))
+        a, va, la, ma, ba = grow_masked(depth - 1, nbuf)
+        b, vb, lb, mb, bb = grow_masked(depth - 1, nbuf)
+        if not (ba or bb):
+            a, va, la, ma, ba = L(mbufs[0]), hs[0], np.zeros(N, bool), hmask[0], True
+        lo = la | lb
+        if op in (eco.ADD, eco.MUL):
+            lo = lo | _both_nan(va, vb)
+        return [a + b, a - b, a * b, a / b][op], eco.f_binop(op, va, vb), lo, ma & mb, True
+
+    for trial in range(12):
+        t, exp, loose, valid, _ = grow_masked(int(rng.integers(2, 5)), 3 if trial % 2 else 6)
+        if not isinstance(t, ec.fused.Lazy) or t.op is None:
+            continue
+        got = t.eval()
+        assert_f64_bits_equal(got.buffer().to_numpy(), exp, nan_by_class_where=loose)
+        assert np.array_equal(got.mask().to_numpy().astype(bool), valid)
+
 
 def _stat(ec, key):
     v = C.c_int64(0)
