@@ -130,18 +130,12 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
         for (int j = 0; j < k; ++j)
             if (p[j] == p[k]) policy = (policy & ~(1u << k)) | (((policy >> j) & 1u) << k);  // one buffer, one policy
     ea.cacheable = static_cast<uint8_t>(policy);
-    // The program compiled for itself (ec_expr_jit.hpp), once it is ready: the value phase as straight-line code; the masks'
-    // AND is then its own small launch.  Until then — and whenever expr_jit is 0 — the interpreter below.
+    // The program compiled for itself (ec_expr_jit.hpp), once it is ready: values and the masks' AND as straight-line code in
+    // one launch.  Until then — and whenever expr_jit is 0 — the interpreter below.
     bool compiled = false;
-    ec_status jst = expr_jit_launch(ea, n, out, s, &compiled);
+    ec_status jst = expr_jit_launch(ea, n, out, out_mask, s, &compiled);
     if (jst != EC_OK) return jst;
-    if (compiled) {
-        if (ea.nmask > 0) {
-            const size_t groups = (n + 15) / 16;
-            k_expr_masks<0><<<grid_capped((groups + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(ea, out_mask, n);
-        }
-        return check_launch("expr(compiled)");
-    }
+    if (compiled) return check_launch("expr(compiled)");
     g_interpreted.fetch_add(1, std::memory_order_relaxed);
     const size_t per_tile = size_t(kBlock) * kExprU;
     const unsigned grid = grid_for((((n - ea.head) >> 1) + per_tile - 1) / per_tile);

@@ -292,12 +292,6 @@ __global__ __launch_bounds__(kBlock) void k_expr_cellwise(ExprArgs ea, double* _
     }
 }
 
-// The masks' AND alone (after the compiled form of a program has written the values).
-template <int UNUSED = 0>
-__global__ __launch_bounds__(kBlock) void k_expr_masks(ExprArgs ea, uint8_t* __restrict__ out_mask, size_t n) {
-    expr_mask_phase(ea, out_mask, n);
-}
-
 using ExprKernel = void (*)(ExprArgs, double*, uint8_t*, size_t);
 
 // kernel for stream load classes (c0 fixed per translation unit; i1, i2, i3 are class INDICES 0..4; nullptr for a

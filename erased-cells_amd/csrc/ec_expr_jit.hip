@@ -118,7 +118,8 @@ std::string expr_jit_source(const ExprArgs& ea) {
     o += "    FOR out[i] = r" + std::to_string(last) + "[i];\n}\n";
     o += "extern \"C\" __global__ __launch_bounds__(256) void ec_expr_jit(const char* p0, const char* p1, const char* p2, const char* p3, ";
     o += scal;
-    o += ", double* __restrict__ out, unsigned long n, unsigned head) {\n"
+    o += ", double* __restrict__ out, unsigned long n, unsigned head, const char* m0, const char* m1, const char* m2, const char* m3, "
+         "unsigned char* __restrict__ out_mask) {\n"
          "    constexpr int U = 2, NC = 2 * U;\n"
          "    const unsigned long npairs = (n - head) >> 1, TILE = 256ul * U;\n"
          "    const unsigned long blk = blockIdx.x, tile = (blk & 1) ? (unsigned long)gridDim.x - 1 - (blk >> 1) : (blk >> 1);  // two fronts\n"
@@ -145,7 +146,23 @@ std::string expr_jit_source(const ExprArgs& ea) {
         o += "            const double a" + K + "[1] = {" + (k < ns ? "cell" + K + "(p" + K + ", i)" : std::string("0.0")) + "};\n";
     }
     o += "            double q[1];\n            run<1>(a0, a1, a2, a3, c0, c1, c2, c3, c4, c5, c6, c7, q);\n"
-         "            __builtin_nontemporal_store(q[0], out + i);\n        }\n    }\n}\n";
+         "            __builtin_nontemporal_store(q[0], out + i);\n        }\n    }\n";
+    if (ea.nmask > 0) {  // the AND of the distinct masks (ec_expr.hpp expr_mask_phase), 16 mask bytes per lane, its own lane map
+        o += "    {\n        const unsigned long ngroups = n / 16, stride = (unsigned long)gridDim.x * 256ul;\n"
+             "        for (unsigned long g = (unsigned long)blockIdx.x * 256ul + threadIdx.x; g < ngroups; g += stride) {\n"
+             "            U4 acc = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};\n";
+        for (int k = 0; k < ea.nmask; ++k) {
+            const bool nt = !((ea.cacheable >> (4 + k)) & 1u);
+            o += std::string("            acc &= ") + (nt ? "__builtin_nontemporal_load(" : "*(") + "(const W8*)m" + std::to_string(k) + " + g);\n";
+        }
+        o += "            __builtin_nontemporal_store(acc, (W8*)out_mask + g);\n        }\n"
+             "        if (blockIdx.x == 0)\n            for (unsigned long i = ngroups * 16 + threadIdx.x; i < n; i += 256ul) {\n"
+             "                unsigned char acc = __builtin_nontemporal_load((const unsigned char*)m0 + i);\n";
+        for (int k = 1; k < ea.nmask; ++k)
+            o += "                acc &= __builtin_nontemporal_load((const unsigned char*)m" + std::to_string(k) + " + i);\n";
+        o += "                __builtin_nontemporal_store(acc, out_mask + i);\n            }\n    }\n";
+    }
+    o += "}\n";
     return o;
 }
 
@@ -303,6 +320,8 @@ std::string key_of(const ExprArgs& ea, const std::string& arch) {
     k.push_back(static_cast<char>(ea.nstreams));
     k.push_back(static_cast<char>(ea.nsteps));
     k.push_back(static_cast<char>(ea.cacheable & ((1u << ea.nstreams) - 1u)));
+    k.push_back(static_cast<char>(ea.nmask));
+    k.push_back(static_cast<char>((ea.cacheable >> 4) & ((1u << ea.nmask) - 1u)));
     return k + arch;
 }
 
@@ -325,7 +344,7 @@ ec_status device_arch(int dev, std::string* arch) {
 
 }  // namespace
 
-ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, hipStream_t s, bool* launched) {
+ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* out_mask, hipStream_t s, bool* launched) {
     *launched = false;
     const int mode = tuning().expr_jit.load();
     if (mode == 0) return EC_OK;
@@ -397,7 +416,10 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, hipStream_t
     for (int k = 0; k < 8; ++k) c[k] = ea.sc[k];
     unsigned long nn = n;
     unsigned head = ea.head;
-    void* params[] = {&p[0], &p[1], &p[2], &p[3], &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &out, &nn, &head};
+    const char* m[4] = {reinterpret_cast<const char*>(ea.m[0]), reinterpret_cast<const char*>(ea.m[1]), reinterpret_cast<const char*>(ea.m[2]),
+                        reinterpret_cast<const char*>(ea.m[3])};
+    void* params[] = {&p[0], &p[1], &p[2], &p[3], &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &out, &nn, &head,
+                      &m[0], &m[1], &m[2], &m[3], &out_mask};
     const size_t npairs = (n - head) >> 1;
     const unsigned grid = grid_for((npairs + 511) / 512);
     st = check_hip(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, s, params, nullptr), "hipModuleLaunchKernel(ec_expr_jit)");

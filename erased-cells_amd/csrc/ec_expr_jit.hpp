@@ -19,16 +19,17 @@
 
 namespace ecd {
 
-// HIP source of the kernel `ec_expr_jit` for the program in `ea` (prog / dt / nstreams / nsteps / cacheable are read).
+// HIP source of the kernel `ec_expr_jit` for the program in `ea` (prog / dt / nstreams / nsteps / nmask / cacheable are read).
 std::string expr_jit_source(const ExprArgs& ea);
 
 // Compile `source` for `arch` ("gfx950") with hiprtc; the code object in `code`, the compiler's log in `log`.
 ec_status expr_jit_compile(const std::string& source, const std::string& arch, std::string* code, std::string* log);
 
-// Run the value phase of the program through its compiled kernel if one is (or, in mode 2, can be made) ready.
+// Run the program (values and, for a masked call, the AND of the masks) through its compiled kernel if one is (or, in mode 2,
+// can be made) ready.
 // *launched = false and EC_OK when the caller should interpret (not compiled yet, compiling, hiprtc missing, capture in
 // progress before the module was loaded).
-ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, hipStream_t s, bool* launched);
+ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* out_mask, hipStream_t s, bool* launched);
 
 int64_t expr_jit_stat(const char* key, bool* known);
 void expr_jit_release();  // ec_shutdown: unload every loaded module
