@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -359,7 +360,13 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* ou
         const std::string key = key_of(ea, arch);
         auto it = g_cache.find(key);
         if (it == g_cache.end()) {
-            if (g_cache.size() >= kMaxPrograms) return EC_OK;  // a process that keeps inventing programs: the rest are interpreted
+            if (g_cache.size() >= kMaxPrograms) {
+                // a process that keeps inventing programs: forget those that never ran long enough to be compiled (they hold a
+                // work counter only); if every entry is a compiled program, the new one is interpreted
+                for (auto c = g_cache.begin(); c != g_cache.end();)
+                    c = c->second->state.load(std::memory_order_acquire) == kNew ? g_cache.erase(c) : std::next(c);
+                if (g_cache.size() >= kMaxPrograms) return EC_OK;
+            }
             it = g_cache.emplace(key, std::make_shared<Entry>()).first;
             it->second->arch = arch;
         }

@@ -452,8 +452,8 @@ def test_expr_random_programs_masks_windows_and_the_eager_chain(ec, pool):
     against the same operators run one by one through the eager HIP path; masked programs AND the streams' masks."""
     host, dev, m, dm = pool
     P = ec.fused
-    rng = np.random.default_rng(4321)
-    for trial in range(60):
+    rng = np.random.default_rng(int(os.environ.get("EC_EXPR_SEED", "4321")))  # EC_EXPR_SEED / EC_EXPR_TRIALS: longer one-off hunts
+    for trial in range(int(os.environ.get("EC_EXPR_TRIALS", "60"))):
         ns = int(rng.integers(1, 5))
         n, off = [(N, 0), (1, 0), (2, 1), (515, 1), (2049, 3)][trial % 5]
         cts = [int(c) for c in rng.integers(0, NT, size=ns)]
@@ -620,7 +620,7 @@ def test_expr_compiled_form_equals_the_interpreter_and_the_oracle(ec, pool):
     interpreted there."""
     host, dev, m, dm = pool
     P, L = ec.fused, ec.lib()
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(int(os.environ.get("EC_EXPR_SEED", "777")))
 
     def both(bufs, scalars, steps):
         L.ec_tune_set(b"expr_jit", 2)
@@ -650,7 +650,7 @@ def test_expr_compiled_form_equals_the_interpreter_and_the_oracle(ec, pool):
     compiles = _stat(ec, b"expr_jit_compiles")
     assert compiles >= NT and _stat(ec, b"expr_jit_failures") == 0
     # random programs, masked every third
-    for trial in range(24):
+    for trial in range(int(os.environ.get("EC_EXPR_JIT_TRIALS", "24"))):
         ns = int(rng.integers(1, 5))
         n, off = [(N, 0), (515, 1), (2049, 3)][trial % 3]
         cts = [int(c) for c in rng.integers(0, NT, size=ns)]
