@@ -5,6 +5,10 @@
 #include <atomic>
 #include <cstring>
 
+#include <limits>
+#include <mutex>
+#include <string>
+
 #include "ec_expr.hpp"
 #include "ec_expr_jit.hpp"
 #include "ec_lattice.hpp"
@@ -75,14 +79,15 @@ static ec_status program_of(ExprArgs& ea, const ec_dtype* dt, int32_t n_streams,
     return EC_OK;
 }
 
-static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n_streams, const uint8_t* const* masks,
-                             const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
-                             double* out, uint8_t* out_mask, hipStream_t s, const char* what) {
-    ExprArgs ea{};
+// Everything of a call but its outputs: the program, the streams, the scalars, the distinct masks, the peel and the load policy.
+// `*aligned`: the vector kernels may run on these pointers (always, unless the unaligned_vector knob is off).
+static ec_status prepare_expr(ExprArgs& ea, bool* aligned_out, int* cls, const ec_dtype* dt, const void* const* p, int32_t n_streams,
+                              const uint8_t* const* masks, const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps,
+                              int32_t n_steps, size_t n, const char* what) {
     ec_status pst = program_of(ea, dt, n_streams, n_scalars, steps, n_steps, what);
     if (pst != EC_OK) return pst;
-    if (!p || !out || (n_scalars > 0 && !scalars)) return set_error(EC_ERR_ARG, "%s: null pointer", what);
-    bool aligned = aligned_to(out, 16);
+    if (!p || (n_scalars > 0 && !scalars)) return set_error(EC_ERR_ARG, "%s: null pointer", what);
+    bool aligned = true;
     for (int k = 0; k < n_streams; ++k) {
         if (!p[k]) return set_error(EC_ERR_ARG, "%s: stream %d is null", what, k);
         ea.p[k] = p[k];
@@ -94,8 +99,6 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
         ea.sc[k] = ec_value_to_f64(&scalars[k]);  // impl $trt<R: Into<CellValue>> (src/buffer.rs:346-352): widened once, here
     }
     if (masks) {
-        if (!out_mask) return set_error(EC_ERR_ARG, "%s: null out_mask", what);
-        aligned = aligned && aligned_to(out_mask, 16);
         for (int k = 0; k < n_streams; ++k) {
             if (!masks[k]) return set_error(EC_ERR_ARG, "%s: null mask %d", what, k);
             bool seen = false;
@@ -106,14 +109,10 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
             }
         }
     }
-    if (!aligned) {
-        k_expr_cellwise<0><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(ea, out, out_mask, n);
-        return check_launch("expr(cellwise)");
-    }
+    *aligned_out = aligned;
     // peel one leading cell when that puts more of the 1-byte streams on even addresses (peel_head's rule)
     unsigned c0 = 0, c1 = 0;
     size_t stream_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int cls[kExprMaxStreams] = {0, 0, 0, 0};
     for (int k = 0; k < n_streams; ++k) {
         const size_t bytes = ecl::size_of(dt[k]);
         c0 += peel_cost(p[k], bytes, 0);
@@ -130,10 +129,29 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
         for (int j = 0; j < k; ++j)
             if (p[j] == p[k]) policy = (policy & ~(1u << k)) | (((policy >> j) & 1u) << k);  // one buffer, one policy
     ea.cacheable = static_cast<uint8_t>(policy);
+    return EC_OK;
+}
+
+static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n_streams, const uint8_t* const* masks,
+                             const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
+                             double* out, uint8_t* out_mask, hipStream_t s, const char* what) {
+    ExprArgs ea{};
+    bool aligned = true;
+    int cls[kExprMaxStreams] = {0, 0, 0, 0};
+    if (!out) return set_error(EC_ERR_ARG, "%s: null pointer", what);
+    if (masks && !out_mask) return set_error(EC_ERR_ARG, "%s: null out_mask", what);
+    ec_status pst = prepare_expr(ea, &aligned, cls, dt, p, n_streams, masks, scalars, n_scalars, steps, n_steps, n, what);
+    if (pst != EC_OK) return pst;
+    aligned = aligned && aligned_to(out, 16) && (!masks || aligned_to(out_mask, 16));
+    if (!aligned) {
+        ea.head = 0;
+        k_expr_cellwise<0><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(ea, out, out_mask, n);
+        return check_launch("expr(cellwise)");
+    }
     // The program compiled for itself (ec_expr_jit.hpp), once it is ready: values and the masks' AND as straight-line code in
     // one launch.  Until then — and whenever expr_jit is 0 — the interpreter below.
     bool compiled = false;
-    ec_status jst = expr_jit_launch(ea, n, out, out_mask, s, &compiled);
+    ec_status jst = expr_jit_launch(ea, n, out, out_mask, nullptr, s, &compiled);
     if (jst != EC_OK) return jst;
     if (compiled) return check_launch("expr(compiled)");
     g_interpreted.fetch_add(1, std::memory_order_relaxed);
@@ -167,6 +185,59 @@ extern "C" ec_status ec_masked_expr(const ec_dtype* dt, const void* const* p, co
     if (n == 0) return EC_OK;
     if (!masks) return set_error(EC_ERR_ARG, "ec_masked_expr: null masks");
     return launch_expr(dt, p, n_streams, masks, scalars, n_scalars, steps, n_steps, n, out, out_mask, static_cast<hipStream_t>(stream), "ec_masked_expr");
+}
+
+// BufferOps::min_max (src/buffer.rs:169-173; masked: src/masked/masked_buffer.rs:208-217) of a program's result without its
+// raster.  Compiled form: the generated kernel folds order keys of the values it computes (ec_expr_jit.hip, reduce variant) —
+// the streams are read, nothing is written but 16 bytes.  Until a program is compiled (and with expr_jit = 0): the program into
+// a temporary from the pool, then ec_min_max of it — two passes, same answer.
+extern "C" ec_status ec_expr_min_max(const ec_dtype* dt, const void* const* p, const uint8_t* const* masks_or_null, int32_t n_streams,
+                                     const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
+                                     ec_value* mn, ec_value* mx, ec_stream stream) {
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    if (!mn || !mx) return set_error(EC_ERR_ARG, "ec_expr_min_max: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ExprArgs ea{};
+    bool aligned = true;
+    int cls[kExprMaxStreams] = {0, 0, 0, 0};
+    {   // the program is checked even when there is nothing to fold
+        ExprArgs probe{};
+        if ((st = program_of(probe, dt, n_streams, n_scalars, steps, n_steps, "ec_expr_min_max")) != EC_OK) return st;
+    }
+    int64_t keys[2] = {~order_key<double>(std::numeric_limits<double>::max()), order_key<double>(std::numeric_limits<double>::lowest())};  // folded from (f64::MAX, f64::MIN)
+    if (n == 0) return ec_min_max_decode(EC_F64, keys, mn, mx);
+    if ((st = prepare_expr(ea, &aligned, cls, dt, p, n_streams, masks_or_null, scalars, n_scalars, steps, n_steps, n, "ec_expr_min_max")) != EC_OK) return st;
+    if (aligned && tuning().expr_jit.load() != 0) {
+        // the two key words live in the stream's reduction scratch (device memory: the kernel folds into them with atomics).
+        // (Not a 16-byte block from the pool: hipMallocAsync carves such a block out of the 2 GiB one the two-pass form has
+        // just returned, and the next 2 GiB request becomes a fresh 130 ms allocation — profiles/r03/expr_kernel.md.)
+        Scratch sc;
+        if ((st = get_scratch(s, &sc)) != EC_OK) return st;
+        std::lock_guard<std::mutex> turn(*sc.mu);
+        int64_t* dkeys = sc.dev_result();
+        st = check_hip(hipMemcpyAsync(dkeys, keys, sizeof keys, hipMemcpyHostToDevice, s), "hipMemcpyAsync(keys)");
+        bool compiled = false;
+        if (st == EC_OK) st = expr_jit_launch(ea, n, nullptr, nullptr, dkeys, s, &compiled);
+        if (st == EC_OK && compiled) st = check_hip(hipMemcpyAsync(keys, dkeys, sizeof keys, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(keys)");
+        if (st == EC_OK) st = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");  // `keys` is this frame's: nothing may be in flight on return
+        if (st != EC_OK) return st;
+        if (compiled) return ec_min_max_decode(EC_F64, keys, mn, mx);
+    }
+    // two passes
+    void *tmp = nullptr, *tmask = nullptr;
+    if ((st = ec_alloc_async(&tmp, n * sizeof(double), s)) != EC_OK) return st;
+    if (masks_or_null && (st = ec_alloc_async(&tmask, n, s)) != EC_OK) {
+        (void)ec_free_async(tmp, s);
+        return st;
+    }
+    st = launch_expr(dt, p, n_streams, masks_or_null, scalars, n_scalars, steps, n_steps, n, static_cast<double*>(tmp),
+                     static_cast<uint8_t*>(tmask), s, "ec_expr_min_max");
+    if (st == EC_OK) st = ec_min_max(EC_F64, tmp, static_cast<const uint8_t*>(tmask), n, mn, mx, stream);
+    const std::string keep = st != EC_OK ? last_error_text() : std::string();
+    (void)ec_free_async(tmp, s);
+    if (tmask) (void)ec_free_async(tmask, s);
+    return st != EC_OK ? set_error_text(st, keep) : EC_OK;
 }
 
 // Diagnostics, no device needed: the source the library would compile for this program (all streams non-temporal), and a

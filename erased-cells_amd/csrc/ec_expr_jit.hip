@@ -7,8 +7,10 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <deque>
 #include <iterator>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -97,7 +99,7 @@ std::string operand(unsigned ref) {
 
 }  // namespace
 
-std::string expr_jit_source(const ExprArgs& ea) {
+std::string expr_jit_source(const ExprArgs& ea, bool reduce) {
     const int ns = ea.nstreams;
     std::string o = "// generated by liberased_cells_hip (ec_expr_jit.hip): one expression program as straight-line code\n";
     o += kPrelude;
@@ -117,6 +119,71 @@ std::string expr_jit_source(const ExprArgs& ea) {
         last = dst;
     }
     o += "    FOR out[i] = r" + std::to_string(last) + "[i];\n}\n";
+    if (reduce) {
+        // min / max of the valid cells' values, nothing stored: a grid-stride loop over the tiles (few workgroups, so that the
+        // two atomics per workgroup at the end do not queue up), lane-local fold of the order keys, LDS tree, atomic max
+        o += "static __device__ __forceinline__ long long okey(double d) {\n"
+             "    const long long b = __builtin_bit_cast(long long, d);\n"
+             "    return b ^ (long long)((unsigned long long)(b >> 63) >> 1);\n}\n";
+        o += "extern \"C\" __global__ __launch_bounds__(256) void ec_expr_jit(const char* p0, const char* p1, const char* p2, const char* p3, ";
+        o += scal;
+        o += ", long long* __restrict__ keys2, unsigned long n, unsigned head, const char* m0, const char* m1, const char* m2, const char* m3, "
+             "long long a0k, long long b0k) {\n"
+             "    constexpr int U = 2, NC = 2 * U;\n"
+             "    const unsigned long npairs = (n - head) >> 1, TILE = 256ul * U, ntiles = (npairs + TILE - 1) / TILE;\n"
+             "    long long a = a0k, b = b0k;  // {~key(min), key(max)} so far: the identities (f64::MAX, f64::MIN) of the reference's fold\n";
+        for (int k2 = 0; k2 < ns; ++k2)
+            o += "    const char* b" + std::to_string(k2) + " = p" + std::to_string(k2) + " + (unsigned long)head * " + std::to_string(ecl::size_of(ea.dt[k2])) + ";\n";
+        o += "    for (unsigned long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {\n"
+             "        const unsigned long base = tile * TILE + threadIdx.x;\n"
+             "        double s0[NC] = {}, s1[NC] = {}, s2[NC] = {}, s3[NC] = {}, o[NC];\n"
+             "        bool valid[NC] = {};\n"
+             "        _Pragma(\"unroll\") for (int j = 0; j < U; ++j) {\n            const unsigned long pr = base + j * 256ul;\n            if (pr < npairs) {\n";
+        for (int k2 = 0; k2 < ns; ++k2) {
+            const std::string K = std::to_string(k2);
+            o += "                ld" + K + "(b" + K + ", pr, s" + K + "[2 * j], s" + K + "[2 * j + 1]);\n";
+        }
+        if (ea.nmask > 0) {
+            o += "                unsigned mk = 0xffffu;\n";
+            for (int k2 = 0; k2 < ea.nmask; ++k2) {
+                const bool nt = !((ea.cacheable >> (4 + k2)) & 1u);
+                o += std::string("                mk &= ") + (nt ? "__builtin_nontemporal_load(" : "*(") + "(const W1*)(m" + std::to_string(k2) + " + head) + pr);\n";
+            }
+            o += "                valid[2 * j] = (mk & 0xffu) != 0; valid[2 * j + 1] = (mk >> 8) != 0;\n";
+        } else {
+            o += "                valid[2 * j] = valid[2 * j + 1] = true;\n";
+        }
+        o += "            }\n        }\n"
+             "        run<NC>(s0, s1, s2, s3, c0, c1, c2, c3, c4, c5, c6, c7, o);\n"
+             "        _Pragma(\"unroll\") for (int i = 0; i < NC; ++i)\n            if (valid[i]) {\n"
+             "                const long long k = okey(o[i]);\n                a = ~k > a ? ~k : a;\n                b = k > b ? k : b;\n            }\n"
+             "    }\n"
+             "    if (blockIdx.x == 0 && threadIdx.x < 2) {  // the peeled head cell (lane 0) and the odd tail cell (lane 1)\n"
+             "        const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;\n"
+             "        const unsigned long i = threadIdx.x == 0 ? 0 : n - 1;\n"
+             "        if (do_it) {\n";
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const std::string K = std::to_string(k2);
+            o += "            const double a" + K + "[1] = {" + (k2 < ns ? "cell" + K + "(p" + K + ", i)" : std::string("0.0")) + "};\n";
+        }
+        o += "            double q[1];\n            run<1>(a0, a1, a2, a3, c0, c1, c2, c3, c4, c5, c6, c7, q);\n            bool ok = true;\n";
+        for (int k2 = 0; k2 < ea.nmask; ++k2)
+            o += "            ok = ok && __builtin_nontemporal_load((const unsigned char*)m" + std::to_string(k2) + " + i) != 0;\n";
+        o += "            if (ok) {\n                const long long k = okey(q[0]);\n                a = ~k > a ? ~k : a;\n                b = k > b ? k : b;\n            }\n"
+             "        }\n    }\n"
+             "    __shared__ long long sa[256], sb[256];\n"
+             "    sa[threadIdx.x] = a;\n    sb[threadIdx.x] = b;\n    __syncthreads();\n"
+             "    for (int w = 128; w > 0; w >>= 1) {\n"
+             "        if ((int)threadIdx.x < w) {\n"
+             "            sa[threadIdx.x] = sa[threadIdx.x + w] > sa[threadIdx.x] ? sa[threadIdx.x + w] : sa[threadIdx.x];\n"
+             "            sb[threadIdx.x] = sb[threadIdx.x + w] > sb[threadIdx.x] ? sb[threadIdx.x + w] : sb[threadIdx.x];\n"
+             "        }\n        __syncthreads();\n    }\n"
+             "    if (threadIdx.x == 0) {\n"
+             "        __hip_atomic_fetch_max(keys2, sa[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+             "        __hip_atomic_fetch_max(keys2 + 1, sb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+             "    }\n}\n";
+        return o;
+    }
     o += "extern \"C\" __global__ __launch_bounds__(256) void ec_expr_jit(const char* p0, const char* p1, const char* p2, const char* p3, ";
     o += scal;
     o += ", double* __restrict__ out, unsigned long n, unsigned head, const char* m0, const char* m1, const char* m2, const char* m3, "
@@ -315,7 +382,7 @@ struct Compiler {
 };
 Compiler g_compiler;
 
-std::string key_of(const ExprArgs& ea, const std::string& arch) {
+std::string key_of(const ExprArgs& ea, const std::string& arch, bool reduce) {
     std::string k(reinterpret_cast<const char*>(ea.prog), sizeof ea.prog);
     k.append(reinterpret_cast<const char*>(ea.dt), sizeof ea.dt);
     k.push_back(static_cast<char>(ea.nstreams));
@@ -323,6 +390,7 @@ std::string key_of(const ExprArgs& ea, const std::string& arch) {
     k.push_back(static_cast<char>(ea.cacheable & ((1u << ea.nstreams) - 1u)));
     k.push_back(static_cast<char>(ea.nmask));
     k.push_back(static_cast<char>((ea.cacheable >> 4) & ((1u << ea.nmask) - 1u)));
+    k.push_back(reduce ? 'r' : 's');
     return k + arch;
 }
 
@@ -345,8 +413,9 @@ ec_status device_arch(int dev, std::string* arch) {
 
 }  // namespace
 
-ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* out_mask, hipStream_t s, bool* launched) {
+ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* out_mask, int64_t* keys2, hipStream_t s, bool* launched) {
     *launched = false;
+    const bool reduce = keys2 != nullptr;
     const int mode = tuning().expr_jit.load();
     if (mode == 0) return EC_OK;
     const int dev = current_device();
@@ -357,7 +426,7 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* ou
     std::shared_ptr<Entry> e;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        const std::string key = key_of(ea, arch);
+        const std::string key = key_of(ea, arch, reduce);
         auto it = g_cache.find(key);
         if (it == g_cache.end()) {
             if (g_cache.size() >= kMaxPrograms) {
@@ -378,7 +447,7 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* ou
         int expected = kNew;
         if (mode >= 2) {  // on the calling thread, now
             if (e->state.compare_exchange_strong(expected, kCompiling)) {
-                e->source = expr_jit_source(ea);
+                e->source = expr_jit_source(ea, reduce);
                 compile_entry(*e);
             } else {
                 while (e->state.load(std::memory_order_acquire) == kCompiling) std::this_thread::yield();  // another caller compiles it
@@ -387,7 +456,7 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* ou
             if (state == kFailed) return set_error_text(EC_ERR_HIP, "ec_expr (expr_jit = 2): " + e->error);
         } else if (work >= (int64_t(1) << 31)) {
             if (e->state.compare_exchange_strong(expected, kCompiling)) {
-                e->source = expr_jit_source(ea);
+                e->source = expr_jit_source(ea, reduce);
                 std::lock_guard<std::mutex> lk(g_mu);
                 g_compiler.ensure();
                 g_queue.push_back(e);
@@ -425,11 +494,21 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* ou
     unsigned head = ea.head;
     const char* m[4] = {reinterpret_cast<const char*>(ea.m[0]), reinterpret_cast<const char*>(ea.m[1]), reinterpret_cast<const char*>(ea.m[2]),
                         reinterpret_cast<const char*>(ea.m[3])};
-    void* params[] = {&p[0], &p[1], &p[2], &p[3], &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &out, &nn, &head,
-                      &m[0], &m[1], &m[2], &m[3], &out_mask};
     const size_t npairs = (n - head) >> 1;
-    const unsigned grid = grid_for((npairs + 511) / 512);
-    st = check_hip(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, s, params, nullptr), "hipModuleLaunchKernel(ec_expr_jit)");
+    if (reduce) {
+        long long a0k = ~order_key<double>(std::numeric_limits<double>::max()), b0k = order_key<double>(std::numeric_limits<double>::lowest());
+        long long* k2 = reinterpret_cast<long long*>(keys2);
+        void* params[] = {&p[0], &p[1], &p[2], &p[3], &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &k2, &nn, &head,
+                          &m[0], &m[1], &m[2], &m[3], &a0k, &b0k};
+        const size_t tiles = (npairs + 511) / 512;
+        const unsigned grid = static_cast<unsigned>(std::min<size_t>(std::max<size_t>(tiles, 1), size_t(device_cus()) * 8));
+        st = check_hip(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, s, params, nullptr), "hipModuleLaunchKernel(ec_expr_jit, reduce)");
+    } else {
+        void* params[] = {&p[0], &p[1], &p[2], &p[3], &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &out, &nn, &head,
+                          &m[0], &m[1], &m[2], &m[3], &out_mask};
+        const unsigned grid = grid_for((npairs + 511) / 512);
+        st = check_hip(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, s, params, nullptr), "hipModuleLaunchKernel(ec_expr_jit)");
+    }
     if (st != EC_OK) return st;
     g_jit_launches.fetch_add(1, std::memory_order_relaxed);
     *launched = true;

@@ -20,7 +20,7 @@
 namespace ecd {
 
 // HIP source of the kernel `ec_expr_jit` for the program in `ea` (prog / dt / nstreams / nsteps / nmask / cacheable are read).
-std::string expr_jit_source(const ExprArgs& ea);
+std::string expr_jit_source(const ExprArgs& ea, bool reduce = false);
 
 // Compile `source` for `arch` ("gfx950") with hiprtc; the code object in `code`, the compiler's log in `log`.
 ec_status expr_jit_compile(const std::string& source, const std::string& arch, std::string* code, std::string* log);
@@ -29,7 +29,9 @@ ec_status expr_jit_compile(const std::string& source, const std::string& arch, s
 // can be made) ready.
 // *launched = false and EC_OK when the caller should interpret (not compiled yet, compiling, hiprtc missing, capture in
 // progress before the module was loaded).
-ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* out_mask, hipStream_t s, bool* launched);
+// `keys2` != nullptr: the REDUCE variant — nothing is stored; the kernel folds {~key(min), key(max)} of the valid cells' values
+// (order keys of f64 under total_cmp, ec_device.hpp order_key) into keys2[0..1] with atomic max (the caller initialises them).
+ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* out_mask, int64_t* keys2, hipStream_t s, bool* launched);
 
 int64_t expr_jit_stat(const char* key, bool* known);
 void expr_jit_release();  // ec_shutdown: unload every loaded module

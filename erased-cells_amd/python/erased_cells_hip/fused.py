@@ -9,6 +9,7 @@ produce bit-identical results (each step is the same rounded f64 op) from a sing
   lazy(buf)                      operator syntax; trees are scheduled onto a program (or the two-level kernel) by `eval()`
   jit(mode)                      how programs run: interpreted / compiled in the background (default) / compiled at once
   program_host, program_host_masked, pinned_empty    numpy arrays in, numpy array out, streamed over PCIe (`ec_host_expr`)
+  program_min_max                (min, max) of a program's result without its raster (`ec_expr_min_max`)
   program_source                 the HIP source the library compiles for a program (no GPU needed)
 """
 from __future__ import annotations
@@ -190,6 +191,26 @@ def program_source(cell_types, n_scalars, steps, arch=None) -> str:
     buf = C.create_string_buffer(need.value)
     check(lib().ec_expr_source(dt, len(cell_types), n_scalars, st, len(steps), arch.encode() if arch else None, buf, need.value, C.byref(need)))
     return buf.value.decode()
+
+
+def program_min_max(streams, scalars, steps):
+    """`(min, max)` of a program's result without its raster (`ec_expr_min_max`): over all cells of plain buffers, over the
+    valid cells (AND of the masks) of masked ones.  Once the library has compiled the program for itself only the streams are
+    read; until then it runs the program into a temporary and reduces that."""
+    from ._ffi import EcExprStep
+    masked = isinstance(streams[0], B.MaskedCellBuffer)
+    assert all(isinstance(o, B.MaskedCellBuffer) == masked for o in streams), "mix of masked and plain operands"
+    bufs = [o.buffer() if masked else o for o in streams]
+    k = len(streams)
+    dt = (C.c_uint8 * k)(*[b.ct for b in bufs])
+    p = (C.c_void_p * k)(*[b.mem.ptr for b in bufs])
+    m = (C.c_void_p * k)(*[o.mask().mem.ptr for o in streams]) if masked else None
+    sc = (B.EcValue * max(1, len(scalars)))(*[B.CellValue.new(x).to_ec() for x in scalars])
+    st = (EcExprStep * len(steps))(*[EcExprStep(*s_) for s_ in steps])
+    n = min(b.len() for b in bufs)
+    mn, mx = B.EcValue(), B.EcValue()
+    check(lib().ec_expr_min_max(dt, p, m, k, sc, len(scalars), st, len(steps), n, C.byref(mn), C.byref(mx), B.stream()))
+    return B.CellValue.from_ec(mn), B.CellValue.from_ec(mx)
 
 
 class _Compiler:

@@ -143,6 +143,9 @@ extern "C" {
     pub fn ec_masked_expr(dt: *const ec_dtype, p: *const *const c_void, masks: *const *const u8, n_streams: i32,
                           scalars: *const ec_value, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32, n: usize,
                           out: *mut f64, out_mask: *mut u8, s: ec_stream) -> ec_status;
+    pub fn ec_expr_min_max(dt: *const ec_dtype, p: *const *const c_void, masks_or_null: *const *const u8, n_streams: i32,
+                           scalars: *const ec_value, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32, n: usize,
+                           mn: *mut ec_value, mx: *mut ec_value, s: ec_stream) -> ec_status;
     pub fn ec_expr_source(dt: *const ec_dtype, n_streams: i32, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32,
                           arch_or_null: *const c_char, buf: *mut c_char, cap: usize, len: *mut usize) -> ec_status;
     pub fn ec_host_alloc(hptr: *mut *mut c_void, bytes: usize) -> ec_status;

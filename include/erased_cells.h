@@ -222,6 +222,16 @@ ec_status ec_expr(const ec_dtype *dt, const void *const *p, int32_t n_streams, c
 ec_status ec_masked_expr(const ec_dtype *dt, const void *const *p, const uint8_t *const *masks, int32_t n_streams,
                          const ec_value *scalars, int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps,
                          size_t n, double *out, uint8_t *out_mask, ec_stream stream);
+/* BufferOps::min_max (src/buffer.rs:169-173; masked: src/masked/masked_buffer.rs:208-217) of a program's RESULT without
+ * its raster: (min, max) under total_cmp of the f64 cells the program computes, over the cells that are valid under the AND
+ * of masks_or_null (NULL: all cells), folded from (f64::MAX, f64::MIN) like every min_max here.  Once the program is
+ * compiled for itself (below) the streams are read and nothing is written — NDVI's statistics cost the bands' 4 B/cell
+ * instead of 4 + 8 + 8; until then (and with expr_jit = 0) the library runs the program into a temporary from its pool and
+ * reduces that: two passes, the same answer.  Synchronous. */
+ec_status ec_expr_min_max(const ec_dtype *dt, const void *const *p, const uint8_t *const *masks_or_null, int32_t n_streams,
+                          const ec_value *scalars, int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps,
+                          size_t n, ec_value *mn, ec_value *mx, ec_stream stream);
+
 /* How ec_expr runs a program.  The kernel that serves every program is an interpreter (a step is decoded once per wave):
  * bound by instruction issue, ≈ 0.04 ms per step over 16384^2 cells beyond the first.  A program is launch-uniform, so
  * the library can also compile it for itself — straight-line code with typed loads, through hiprtc (resolved lazily;

@@ -881,6 +881,47 @@ except Exception as e:
     assert "REFUSED:" in r.stdout and "libhiprtc" in r.stdout, r.stdout
 
 
+def test_expr_min_max_without_the_raster(ec, pool):
+    """`ec_expr_min_max`: (min, max) of a program's result equals `min_max()` of the materialised result — bits and cell type —
+    for plain and masked streams, through the two-pass form (expr_jit = 0) and the compiled reduce kernel (expr_jit = 2),
+    odd windows, results that contain NaN (0/0: the x86 default NaN is negative, so it is the minimum under total_cmp),
+    nothing valid at all (the fold's identities)."""
+    host, dev, m, dm = pool
+    P, L = ec.fused, ec.lib()
+    S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+    ndvi = [(eco.SUB, S(0), S(1), 0), (eco.ADD, S(0), S(1), 1), (eco.DIV, R(0), R(1), 0)]
+    cases = [([eco.U16, eco.U16], ndvi, []), ([eco.U8, eco.I8], ndvi, []),  # u8 / i8 bands hold zeros: 0/0 cells
+             ([eco.F32, eco.I16, eco.F64], [(eco.MUL, S(0), K(0), 0), (eco.SUB, R(0), S(1), 1), (eco.DIV, R(1), S(2), 0), (eco.ADD, R(0), K(1), 2)], [2.5, -7.0]),
+             ([eco.I64], [(eco.MUL, S(0), K(0), 0)], [0.5])]
+    for cts, steps, scalars in cases:
+        for n, off in ((N, 0), (2049, 3), (1, 0), (2, 1)):
+            for masked in (False, True):
+                bufs = [dev[ct].shard(off + k, n) for k, ct in enumerate(cts)]
+                if masked:
+                    bufs = [ec.MaskedCellBuffer(b, dm[k % 2].shard(off + k, n)) for k, b in enumerate(bufs)]
+                want = P.program(bufs, scalars, steps).min_max()
+                for mode in (0, 2):
+                    with P.jit(mode):
+                        j0 = _stat(ec, b"expr_jit_launches")
+                        got = P.program_min_max(bufs, scalars, steps)
+                        assert (_stat(ec, b"expr_jit_launches") - j0 == 1) == (mode == 2)
+                    assert (got[0].ct, got[1].ct) == (ec.Float64, ec.Float64)
+                    assert (got[0].bits(), got[1].bits()) == (want[0].bits(), want[1].bits()), (cts, n, off, masked, mode, got, want)
+    # nothing valid: the identities of the fold, (f64::MAX, f64::MIN)
+    x = ec.MaskedCellBuffer(dev[eco.U16].shard(0, N), ec.Mask.fill(N, False))
+    for mode in (0, 2):
+        with P.jit(mode):
+            mn, mx = P.program_min_max([x], [2.0], [(eco.MUL, S(0), K(0), 0)])
+        assert float(mn.value) == np.finfo(np.float64).max and float(mx.value) == np.finfo(np.float64).min
+    # against the oracle on one case
+    h0, h1 = host[eco.U16][:N], host[eco.U16][1:N + 1]
+    vals = eco.f_binop(eco.DIV, eco.f_binop(eco.SUB, h0, h1), eco.f_binop(eco.ADD, h0, h1))
+    emn, emx = eco.f_min_max(vals, None)
+    with P.jit(2):
+        mn, mx = P.program_min_max([dev[eco.U16].shard(0, N), dev[eco.U16].shard(1, N)], [], ndvi)
+    assert (mn.bits(), mx.bits()) == (emn.bits(), emx.bits())
+
+
 def test_expr_rejects_malformed_programs(ec, pool):
     host, dev, _, _ = pool
     L, E = ec.lib(), ec._ffi
