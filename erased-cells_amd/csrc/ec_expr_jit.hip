@@ -91,6 +91,18 @@ void emit_loader(std::string& o, int k, int dt, bool nt) {
          kCellType[dt] + "*)p + i); }\n";
 }
 
+// pairs per lane per tile of the REDUCE variant (EC_EXPR_REDUCE_U for experiments).  Measured, NDVI statistics at 16384²:
+// 2 pairs 0.443 ms, 4 pairs 0.491, 8 pairs 0.636 — the kernel is bound by instruction issue (the IEEE divide), not by the
+// loads in flight, and more cells per lane only cost occupancy (profiles/r03/expr_kernel.md)
+int reduce_u() {
+    static const int u = [] {
+        const char* e = std::getenv("EC_EXPR_REDUCE_U");
+        const int v = e ? std::atoi(e) : 2;
+        return v == 1 || v == 2 || v == 4 || v == 8 ? v : 2;
+    }();
+    return u;
+}
+
 std::string operand(unsigned ref) {
     if (ref < unsigned(kRefReg0)) return "s" + std::to_string(ref) + "[i]";
     if (ref < unsigned(kRefScalar0)) return "r" + std::to_string(ref - kRefReg0) + "[i]";
@@ -129,9 +141,10 @@ std::string expr_jit_source(const ExprArgs& ea, bool reduce) {
         o += scal;
         o += ", long long* __restrict__ keys2, unsigned long n, unsigned head, const char* m0, const char* m1, const char* m2, const char* m3, "
              "long long a0k, long long b0k) {\n"
-             "    constexpr int U = 2, NC = 2 * U;\n"
+             "    constexpr int U = " + std::to_string(reduce_u()) + ", NC = 2 * U;\n"
              "    const unsigned long npairs = (n - head) >> 1, TILE = 256ul * U, ntiles = (npairs + TILE - 1) / TILE;\n"
-             "    long long a = a0k, b = b0k;  // {~key(min), key(max)} so far: the identities (f64::MAX, f64::MIN) of the reference's fold\n";
+             "    long long a = a0k, b = b0k;  // {~key(min), key(max)} so far: the identities (f64::MAX, f64::MIN) of the reference's fold\n"
+             "    double fmin = 1.7976931348623157e308, fmax = -1.7976931348623157e308;  // the same identities, by value\n";
         for (int k2 = 0; k2 < ns; ++k2)
             o += "    const char* b" + std::to_string(k2) + " = p" + std::to_string(k2) + " + (unsigned long)head * " + std::to_string(ecl::size_of(ea.dt[k2])) + ";\n";
         o += "    for (unsigned long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {\n"
@@ -155,9 +168,20 @@ std::string expr_jit_source(const ExprArgs& ea, bool reduce) {
         }
         o += "            }\n        }\n"
              "        run<NC>(s0, s1, s2, s3, c0, c1, c2, c3, c4, c5, c6, c7, o);\n"
-             "        _Pragma(\"unroll\") for (int i = 0; i < NC; ++i)\n            if (valid[i]) {\n"
-             "                const long long k = okey(o[i]);\n                a = ~k > a ? ~k : a;\n                b = k > b ? k : b;\n            }\n"
+             // a tile without a NaN or a zero among its valid values (the common case) is folded by VALUE — v_min_f64 / v_max_f64,
+             // 3 instructions per cell instead of the 13 of the key fold: by value and by total_cmp agree when no two bit patterns
+             // compare equal and nothing is unordered
+             "        bool special = false;\n"
+             "        _Pragma(\"unroll\") for (int i = 0; i < NC; ++i) special = special || (valid[i] && __builtin_amdgcn_class(o[i], 0x63));\n"
+             "        if (__builtin_amdgcn_ballot_w64(special) == 0) {\n"
+             "            _Pragma(\"unroll\") for (int i = 0; i < NC; ++i) {\n"
+             "                fmin = __builtin_fmin(fmin, valid[i] ? o[i] : fmin);\n                fmax = __builtin_fmax(fmax, valid[i] ? o[i] : fmax);\n            }\n"
+             "        } else {\n"
+             "            _Pragma(\"unroll\") for (int i = 0; i < NC; ++i)\n                if (valid[i]) {\n"
+             "                    const long long k = okey(o[i]);\n                    a = ~k > a ? ~k : a;\n                    b = k > b ? k : b;\n                }\n"
+             "        }\n"
              "    }\n"
+             "    {\n        const long long k0 = okey(fmin), k1 = okey(fmax);\n        a = ~k0 > a ? ~k0 : a;\n        b = k1 > b ? k1 : b;\n    }\n"
              "    if (blockIdx.x == 0 && threadIdx.x < 2) {  // the peeled head cell (lane 0) and the odd tail cell (lane 1)\n"
              "        const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;\n"
              "        const unsigned long i = threadIdx.x == 0 ? 0 : n - 1;\n"
@@ -500,7 +524,8 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* ou
         long long* k2 = reinterpret_cast<long long*>(keys2);
         void* params[] = {&p[0], &p[1], &p[2], &p[3], &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &k2, &nn, &head,
                           &m[0], &m[1], &m[2], &m[3], &a0k, &b0k};
-        const size_t tiles = (npairs + 511) / 512;
+        const size_t per_tile = size_t(256) * reduce_u();
+        const size_t tiles = (npairs + per_tile - 1) / per_tile;
         const unsigned grid = static_cast<unsigned>(std::min<size_t>(std::max<size_t>(tiles, 1), size_t(device_cus()) * 8));
         st = check_hip(hipModuleLaunchKernel(fn, grid, 1, 1, 256, 1, 1, 0, s, params, nullptr), "hipModuleLaunchKernel(ec_expr_jit, reduce)");
     } else {
