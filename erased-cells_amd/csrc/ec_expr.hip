@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 #include <limits>
@@ -247,7 +248,8 @@ extern "C" ec_status ec_expr_source(const ec_dtype* dt, int32_t n_streams, int32
     ExprArgs ea{};
     ec_status st = program_of(ea, dt, n_streams, n_scalars, steps, n_steps, "ec_expr_source");
     if (st != EC_OK) return st;
-    const std::string src = expr_jit_source(ea);
+    const char* variant = std::getenv("EC_EXPR_SOURCE_VARIANT");  // "reduce": the min_max variant (ec_expr_min_max) instead
+    const std::string src = expr_jit_source(ea, variant && !std::strcmp(variant, "reduce"));
     if (len) *len = src.size() + 1;
     if (buf && cap > 0) {
         const size_t k = src.size() < cap - 1 ? src.size() : cap - 1;

@@ -48,6 +48,20 @@ static __device__ __forceinline__ double fixnan(double t, double a, double b) {
                 : (b != b) ? (__builtin_bit_cast(u64, b) | 0x0008000000000000ull) : 0xFFF8000000000000ull;
     return (t != t) ? __builtin_bit_cast(double, f) : t;
 }
+// The quotient of two integers of magnitude ≤ 131070 held as f64 (≤ 16-bit cells, their sums and differences): v_rcp_f64, one
+// Newton step, the quotient, its exact residual and one correction — ec_device.hpp div_small_int, proven against the IEEE
+// expansion on that whole square (tools/div_small_check.hip); b == 0 gives what the f64 divide gives: ±inf, the x86 default
+// NaN for 0/0 (an integer-derived zero is +0).
+static __device__ __forceinline__ double divs(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    const double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    q = __builtin_fma(r, y, q);
+    const double z = a == 0.0 ? __builtin_bit_cast(double, 0xFFF8000000000000ull) : (a > 0.0 ? __builtin_inf() : -__builtin_inf());
+    return b == 0.0 ? z : q;
+}
 // tested once per pair of cells (v_cmp_u_f64 r0, r1 is true when either is NaN), handled out of line, wave-uniform branch
 #define NANFIX(A, B)                                                                                  \
     {                                                                                                 \
@@ -91,14 +105,15 @@ void emit_loader(std::string& o, int k, int dt, bool nt) {
          kCellType[dt] + "*)p + i); }\n";
 }
 
-// pairs per lane per tile of the REDUCE variant (EC_EXPR_REDUCE_U for experiments).  Measured, NDVI statistics at 16384²:
-// 2 pairs 0.443 ms, 4 pairs 0.491, 8 pairs 0.636 — the kernel is bound by instruction issue (the IEEE divide), not by the
-// loads in flight, and more cells per lane only cost occupancy (profiles/r03/expr_kernel.md)
+// pairs per lane per tile of the REDUCE variant (EC_EXPR_REDUCE_U for experiments).  Nothing is stored, so the loads in flight
+// are all the memory-level parallelism there is.  Measured, NDVI / EVI statistics at 16384² with the full-tile path (every load
+// of a tile issued before the first use): 2 pairs 0.413 / 0.527 ms, 4 pairs 0.378 / 0.497, 8 pairs 0.375 / 0.600
+// (profiles/r03/expr_kernel.md).
 int reduce_u() {
     static const int u = [] {
         const char* e = std::getenv("EC_EXPR_REDUCE_U");
-        const int v = e ? std::atoi(e) : 2;
-        return v == 1 || v == 2 || v == 4 || v == 8 ? v : 2;
+        const int v = e ? std::atoi(e) : 4;
+        return v == 1 || v == 2 || v == 4 || v == 8 ? v : 4;
     }();
     return u;
 }
@@ -123,11 +138,26 @@ std::string expr_jit_source(const ExprArgs& ea, bool reduce) {
     o += ", double (&out)[N]) {\n    double r0[N], r1[N], r2[N], r3[N], t[N];\n";
     static const char* const kOp[4] = {"+", "-", "*", "/"};
     unsigned last = 0;
+    // What the program PROVES about its values, used for one thing: a divide whose operands are both integers of magnitude
+    // ≤ 131070 — cells of ≤ 16-bit integer streams (class 1) or a sum / difference of two such cells (class 2) — is the short
+    // exact divide instead of the IEEE expansion (NDVI's divide; the interpreter cannot know, the generator reads the program).
+    auto small_stream = [&](unsigned ref) { return ref < unsigned(ea.nstreams) && (ea.dt[ref] == EC_U8 || ea.dt[ref] == EC_I8 || ea.dt[ref] == EC_U16 || ea.dt[ref] == EC_I16); };
+    int reg_class[kExprRegs] = {0, 0, 0, 0};
+    auto small_operand = [&](unsigned ref) {
+        if (ref < unsigned(kRefReg0)) return small_stream(ref);
+        if (ref < unsigned(kRefScalar0)) return reg_class[ref - kRefReg0] != 0;
+        return false;
+    };
     for (int k = 0; k < ea.nsteps; ++k) {
         const unsigned step = static_cast<unsigned>(ea.prog[k >> 2] >> (16 * (k & 3))) & 0xffffu;
         const unsigned op = step & 3u, dst = (step >> 2) & 3u, a = (step >> 4) & 15u, b = (step >> 8) & 15u;
         const std::string A = operand(a), B = operand(b);
-        o += "    FOR t[i] = " + A + " " + kOp[op] + " " + B + ";\n    NANFIX(" + A + ", " + B + ")\n    FOR r" + std::to_string(dst) + "[i] = t[i];\n";
+        if (op == unsigned(EC_DIV) && small_operand(a) && small_operand(b))
+            o += "    FOR t[i] = divs(" + A + ", " + B + ");\n    FOR r" + std::to_string(dst) + "[i] = t[i];\n";
+        else
+            o += "    FOR t[i] = " + A + " " + kOp[op] + " " + B + ";\n    NANFIX(" + A + ", " + B + ")\n    FOR r" + std::to_string(dst) + "[i] = t[i];\n";
+        // class of the register written: a sum or difference of two ≤ 16-bit integer CELLS stays within ±131070
+        reg_class[dst] = ((op == unsigned(EC_ADD) || op == unsigned(EC_SUB)) && a < unsigned(kRefReg0) && b < unsigned(kRefReg0) && small_stream(a) && small_stream(b)) ? 2 : 0;
         last = dst;
     }
     o += "    FOR out[i] = r" + std::to_string(last) + "[i];\n}\n";
@@ -151,23 +181,30 @@ std::string expr_jit_source(const ExprArgs& ea, bool reduce) {
              "        const unsigned long base = tile * TILE + threadIdx.x;\n"
              "        double s0[NC] = {}, s1[NC] = {}, s2[NC] = {}, s3[NC] = {}, o[NC];\n"
              "        bool valid[NC] = {};\n"
-             "        _Pragma(\"unroll\") for (int j = 0; j < U; ++j) {\n            const unsigned long pr = base + j * 256ul;\n            if (pr < npairs) {\n";
-        for (int k2 = 0; k2 < ns; ++k2) {
-            const std::string K = std::to_string(k2);
-            o += "                ld" + K + "(b" + K + ", pr, s" + K + "[2 * j], s" + K + "[2 * j + 1]);\n";
-        }
-        if (ea.nmask > 0) {
-            o += "                unsigned mk = 0xffffu;\n";
-            for (int k2 = 0; k2 < ea.nmask; ++k2) {
-                const bool nt = !((ea.cacheable >> (4 + k2)) & 1u);
-                o += std::string("                mk &= ") + (nt ? "__builtin_nontemporal_load(" : "*(") + "(const W1*)(m" + std::to_string(k2) + " + head) + pr);\n";
+             "        const bool full = tile * TILE + TILE <= npairs;  // a full tile loads without guards: every load is issued before the first use\n";
+        auto emit_tile_loads = [&](const char* ind) {
+            for (int k2 = 0; k2 < ns; ++k2) {
+                const std::string K = std::to_string(k2);
+                o += std::string(ind) + "ld" + K + "(b" + K + ", pr, s" + K + "[2 * j], s" + K + "[2 * j + 1]);\n";
             }
-            o += "                valid[2 * j] = (mk & 0xffu) != 0; valid[2 * j + 1] = (mk >> 8) != 0;\n";
-        } else {
-            o += "                valid[2 * j] = valid[2 * j + 1] = true;\n";
-        }
-        o += "            }\n        }\n"
-             "        run<NC>(s0, s1, s2, s3, c0, c1, c2, c3, c4, c5, c6, c7, o);\n"
+            if (ea.nmask > 0) {
+                o += std::string(ind) + "unsigned mk = 0xffffu;\n";
+                for (int k2 = 0; k2 < ea.nmask; ++k2) {
+                    const bool nt = !((ea.cacheable >> (4 + k2)) & 1u);
+                    o += std::string(ind) + "mk &= " + (nt ? "__builtin_nontemporal_load(" : "*(") + "(const W1*)(m" + std::to_string(k2) + " + head) + pr);\n";
+                }
+                o += std::string(ind) + "valid[2 * j] = (mk & 0xffu) != 0; valid[2 * j + 1] = (mk >> 8) != 0;\n";
+            } else {
+                o += std::string(ind) + "valid[2 * j] = valid[2 * j + 1] = true;\n";
+            }
+        };
+        o += "        if (full) {\n            _Pragma(\"unroll\") for (int j = 0; j < U; ++j) {\n                const unsigned long pr = base + j * 256ul;\n";
+        emit_tile_loads("                ");
+        o += "            }\n        } else {\n            _Pragma(\"unroll\") for (int j = 0; j < U; ++j) {\n                const unsigned long pr = base + j * 256ul;\n"
+             "                if (pr < npairs) {\n";
+        emit_tile_loads("                    ");
+        o += "                }\n            }\n        }\n";
+        o += "        run<NC>(s0, s1, s2, s3, c0, c1, c2, c3, c4, c5, c6, c7, o);\n"
              // a tile without a NaN or a zero among its valid values (the common case) is folded by VALUE — v_min_f64 / v_max_f64,
              // 3 instructions per cell instead of the 13 of the key fold: by value and by total_cmp agree when no two bit patterns
              // compare equal and nothing is unordered
@@ -220,15 +257,22 @@ std::string expr_jit_source(const ExprArgs& ea, bool reduce) {
          "    double s0[NC] = {}, s1[NC] = {}, s2[NC] = {}, s3[NC] = {}, o[NC];\n";
     for (int k = 0; k < ns; ++k)
         o += "    const char* b" + std::to_string(k) + " = p" + std::to_string(k) + " + (unsigned long)head * " + std::to_string(ecl::size_of(ea.dt[k])) + ";\n";
-    o += "    _Pragma(\"unroll\") for (int j = 0; j < U; ++j) {\n        const unsigned long pr = base + j * 256ul;\n        if (pr < npairs) {\n";
+    // a full tile loads without guards (every load of the tile is issued before the first use); the last tile guards each pair
+    o += "    const bool full = tile * TILE + TILE <= npairs;\n"
+         "    if (full) {\n        _Pragma(\"unroll\") for (int j = 0; j < U; ++j) {\n            const unsigned long pr = base + j * 256ul;\n";
     for (int k = 0; k < ns; ++k) {
         const std::string K = std::to_string(k);
         o += "            ld" + K + "(b" + K + ", pr, s" + K + "[2 * j], s" + K + "[2 * j + 1]);\n";
     }
-    o += "        }\n    }\n"
+    o += "        }\n    } else {\n        _Pragma(\"unroll\") for (int j = 0; j < U; ++j) {\n            const unsigned long pr = base + j * 256ul;\n            if (pr < npairs) {\n";
+    for (int k = 0; k < ns; ++k) {
+        const std::string K = std::to_string(k);
+        o += "                ld" + K + "(b" + K + ", pr, s" + K + "[2 * j], s" + K + "[2 * j + 1]);\n";
+    }
+    o += "            }\n        }\n    }\n"
          "    run<NC>(s0, s1, s2, s3, c0, c1, c2, c3, c4, c5, c6, c7, o);\n"
          "    _Pragma(\"unroll\") for (int j = 0; j < U; ++j) {\n        const unsigned long pr = base + j * 256ul;\n"
-         "        if (pr < npairs) __builtin_nontemporal_store(D2{o[2 * j], o[2 * j + 1]}, op + pr);\n    }\n"
+         "        if (full || pr < npairs) __builtin_nontemporal_store(D2{o[2 * j], o[2 * j + 1]}, op + pr);\n    }\n"
          "    if (blockIdx.x == 0 && threadIdx.x < 2) {  // the peeled head cell (lane 0) and the odd tail cell (lane 1)\n"
          "        const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;\n"
          "        const unsigned long i = threadIdx.x == 0 ? 0 : n - 1;\n"

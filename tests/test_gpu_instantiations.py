@@ -922,6 +922,47 @@ def test_expr_min_max_without_the_raster(ec, pool):
     assert (mn.bits(), mx.bits()) == (emn.bits(), emx.bits())
 
 
+def test_compiled_programs_use_the_short_divide_only_where_it_is_exact(ec):
+    """The generator turns a divide into the short exact divide when the program proves both operands integers of magnitude
+    ≤ 131070 (≤ 16-bit integer cells, their sums and differences).  Compiled against interpreted (the IEEE expansion), compared
+    on the device: every u8 / i8 pair, every u16 and i16 denominator against 2048 numerators (extremes included), NDVI-shaped
+    sums and differences over the same operand sets — zero divisors and 0/0 included."""
+    P, L = ec.fused, ec.lib()
+    S, R = (lambda k: k), (lambda k: 4 + k)
+    rng = np.random.default_rng(11)
+
+    def grid_of(dt, rows):
+        info = np.iinfo(dt)
+        den = np.arange(info.min, info.max + 1, dtype=np.int64).astype(dt)
+        num = np.concatenate([np.array([info.min, info.max, 0, 1, info.max - 1], dtype=np.int64),
+                              rng.integers(info.min, info.max + 1, rows - 5)]).astype(dt)
+        return np.repeat(num, den.size), np.tile(den, num.size)
+
+    sets = []
+    for dt in (np.uint8, np.int8):
+        sets.append(grid_of(dt, 256 if dt == np.uint8 else 256))
+    for dt in (np.uint16, np.int16):
+        sets.append(grid_of(dt, 2048))
+    a8, b8 = sets[0]
+    sets.append((a8.astype(np.uint16) * 257, np.tile(np.arange(256, dtype=np.int8), 256)))  # mixed widths: u16 over i8
+    divide = [(eco.DIV, S(0), S(1), 0)]
+    ndvi = [(eco.SUB, S(0), S(1), 0), (eco.ADD, S(0), S(1), 1), (eco.DIV, R(0), R(1), 0)]
+    for ha, hb in sets:
+        da, db = ec.CellBuffer.from_vec(ha), ec.CellBuffer.from_vec(hb)
+        for prog in (divide, ndvi):
+            src = P.program_source([da.ct, db.ct], 0, prog)
+            assert "= divs(" in src and " / " not in src[src.index("void run("):src.index("extern \"C\"")]
+            with P.jit(2):
+                compiled = P.program([da, db], [], prog)
+            with P.jit(0):
+                interpreted = P.program([da, db], [], prog)
+            assert compiled == interpreted, (ha.dtype, hb.dtype, prog)
+    # a wider cell type on either side, or a register that is not a sum / difference of cells: the IEEE divide stays
+    assert "= divs(" not in P.program_source([ec.UInt16, ec.UInt32], 0, divide)
+    assert "= divs(" not in P.program_source([ec.UInt16, ec.UInt16], 1, [(eco.MUL, S(0), 8, 0), (eco.DIV, R(0), S(1), 0)])
+    assert "= divs(" not in P.program_source([ec.UInt16, ec.UInt16], 0, [(eco.SUB, S(0), S(1), 0), (eco.ADD, R(0), S(1), 1), (eco.DIV, R(1), S(0), 0)])
+
+
 def test_expr_rejects_malformed_programs(ec, pool):
     host, dev, _, _ = pool
     L, E = ec.lib(), ec._ffi
