@@ -867,6 +867,45 @@ inline MaskedCellBuffer program(const std::vector<const MaskedCellBuffer*>& stre
 }
 
 
+// (min, max) of a program's result without its raster (ec_expr_min_max): once the library has compiled the program for itself
+// only the streams are read; until then it runs the program into a temporary and reduces that.  Typed Float64.
+inline std::pair<CellValue, CellValue> program_min_max(const std::vector<const CellBuffer*>& streams, const std::vector<CellValue>& scalars,
+                                                      const std::vector<ec_expr_step>& steps) {
+    size_t n = streams.empty() ? 0 : streams[0]->len();
+    std::vector<ec_dtype> dt;
+    std::vector<const void*> p;
+    for (const CellBuffer* b : streams) {
+        n = std::min(n, b->len());
+        dt.push_back(static_cast<ec_dtype>(b->cell_type()));
+        p.push_back(b->ptr());
+    }
+    std::vector<ec_value> sc;
+    for (const CellValue& v : scalars) sc.push_back(v.raw());
+    ec_value mn{}, mx{};
+    check(ec_expr_min_max(dt.data(), p.data(), nullptr, static_cast<int32_t>(streams.size()), sc.data(), static_cast<int32_t>(sc.size()),
+                          steps.data(), static_cast<int32_t>(steps.size()), n, &mn, &mx, current_stream()));
+    return {CellValue(mn), CellValue(mx)};
+}
+inline std::pair<CellValue, CellValue> program_min_max(const std::vector<const MaskedCellBuffer*>& streams, const std::vector<CellValue>& scalars,
+                                                      const std::vector<ec_expr_step>& steps) {
+    size_t n = streams.empty() ? 0 : streams[0]->len();
+    std::vector<ec_dtype> dt;
+    std::vector<const void*> p;
+    std::vector<const uint8_t*> m;
+    for (const MaskedCellBuffer* b : streams) {
+        n = std::min(n, b->len());
+        dt.push_back(static_cast<ec_dtype>(b->cell_type()));
+        p.push_back(b->buffer().ptr());
+        m.push_back(b->mask().ptr());
+    }
+    std::vector<ec_value> sc;
+    for (const CellValue& v : scalars) sc.push_back(v.raw());
+    ec_value mn{}, mx{};
+    check(ec_expr_min_max(dt.data(), p.data(), m.data(), static_cast<int32_t>(streams.size()), sc.data(), static_cast<int32_t>(sc.size()),
+                          steps.data(), static_cast<int32_t>(steps.size()), n, &mn, &mx, current_stream()));
+    return {CellValue(mn), CellValue(mx)};
+}
+
 // Host memory in, host memory out (ec_host_expr): the same program over HOST arrays of n cells each — `arrays[k]` is
 // {cell type, pointer} — streamed through the GPU in chunks with upload, kernel and download overlapped; PCIe-bound
 // (≈ 6 Gcells/s at 16384² against ≈ 1.2 for from_vec + operator + to_vec).  Page-locked buffers (ec_host_alloc) are copied

@@ -242,3 +242,23 @@ pub fn program_host_masked(streams: &[HostCells], scalars: &[CellValue], steps: 
     );
     (out, mask.into_iter().map(|b| b != 0).collect())
 }
+
+/// `(min, max)` of a program's result without its raster (`ec_expr_min_max`): once the library has compiled the program for
+/// itself only the streams are read; until then it runs the program into a temporary and reduces that.  Both values are
+/// `Float64`; an empty input gives the fold's identities `(f64::MAX, f64::MIN)`, like `BufferOps::min_max`.
+pub fn program_min_max(streams: &[&CellBuffer], scalars: &[CellValue], steps: &[Step]) -> (CellValue, CellValue) {
+    assert!(!streams.is_empty() && streams.len() <= EC_EXPR_MAX_STREAMS, "1..=4 buffers");
+    let n = streams.iter().map(|b| b.len()).min().unwrap_or(0);
+    let dt: Vec<u8> = streams.iter().map(|b| b.cell_type() as u8).collect();
+    let p: Vec<*const c_void> = streams.iter().map(|b| b.dev_ptr()).collect();
+    let sc: Vec<ec_value> = scalars.iter().map(|v| v.to_ffi()).collect();
+    let (mut mn, mut mx) = (CellValue::Float64(0.0).to_ffi(), CellValue::Float64(0.0).to_ffi());
+    must(
+        unsafe {
+            ec_expr_min_max(dt.as_ptr(), p.as_ptr(), std::ptr::null(), streams.len() as i32, sc.as_ptr(), sc.len() as i32, steps.as_ptr(),
+                            steps.len() as i32, n, &mut mn, &mut mx, stream())
+        },
+        "ec_expr_min_max",
+    );
+    (CellValue::from_ffi(&mn), CellValue::from_ffi(&mx))
+}
