@@ -154,6 +154,8 @@ std::string expr_jit_source(const ExprArgs& ea, bool reduce) {
         const std::string A = operand(a), B = operand(b);
         if (op == unsigned(EC_DIV) && small_operand(a) && small_operand(b))
             o += "    FOR t[i] = divs(" + A + ", " + B + ");\n    FOR r" + std::to_string(dst) + "[i] = t[i];\n";
+        else if (op != unsigned(EC_DIV) && small_operand(a) && small_operand(b))  // finite integers in, a finite number out: no NaN to fix
+            o += "    FOR r" + std::to_string(dst) + "[i] = " + A + " " + kOp[op] + " " + B + ";\n";
         else
             o += "    FOR t[i] = " + A + " " + kOp[op] + " " + B + ";\n    NANFIX(" + A + ", " + B + ")\n    FOR r" + std::to_string(dst) + "[i] = t[i];\n";
         // class of the register written: a sum or difference of two ≤ 16-bit integer CELLS stays within ±131070

@@ -23,12 +23,14 @@ def test_source_is_the_program_written_out():
     assert 'extern "C" __global__ __launch_bounds__(256) void ec_expr_jit(' in src
     # the steps, in the program's order, on the operands the program names
     body = src[src.index("static __device__ __forceinline__ void run("):]
-    want = ["t[i] = s0[i] - s1[i];", "t[i] = r0[i] * c0;", "t[i] = s1[i] * c1;", "t[i] = s0[i] + r1[i];", "t[i] = s2[i] * c2;",
+    want = ["r0[i] = s0[i] - s1[i];", "t[i] = r0[i] * c0;", "t[i] = s1[i] * c1;", "t[i] = s0[i] + r1[i];", "t[i] = s2[i] * c2;",
             "t[i] = r1[i] - r2[i];", "t[i] = r1[i] + c3;", "t[i] = r0[i] / r1[i];"]
     at = 0
     for line in want:
         at = body.index(line, at) + 1
-    assert body.count("NANFIX(") == len(EVI)  # every step keeps cv_bin_op!'s NaN rule
+    # every step keeps cv_bin_op!'s NaN rule — except the first: a difference of u16 and i8 cells is a finite integer, which the
+    # generator can read off the program (and a divide of such values would be the short exact divide)
+    assert body.count("NANFIX(") == len(EVI) - 1
     # typed loads: a pair of u16 cells is one 32-bit word, a pair of i8 cells one 16-bit word taken apart with shifts, f64 as is
     assert "(const W2*)b + pr" in src and "(int)(w << 24) >> 24" in src and "__builtin_bit_cast(double, x)" in src
     assert src.count("__builtin_nontemporal_load((const W") == 3, "every stream of the diagnostic source is non-temporal"
