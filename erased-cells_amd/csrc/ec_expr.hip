@@ -192,6 +192,59 @@ extern "C" ec_status ec_masked_expr(const ec_dtype* dt, const void* const* p, co
 // raster.  Compiled form: the generated kernel folds order keys of the values it computes (ec_expr_jit.hip, reduce variant) —
 // the streams are read, nothing is written but 16 bytes.  Until a program is compiled (and with expr_jit = 0): the program into
 // a temporary from the pool, then ec_min_max of it — two passes, same answer.
+// {~key(min), key(max)} of the program's result into DEVICE memory `keys2_dev`, asynchronously on `s` — the payload of the
+// sharded reduction (one element-wise MAX all-reduce combines the shards), and what ec_expr_min_max waits for and decodes.
+static const int64_t kF64Identities[2] = {~order_key<double>(std::numeric_limits<double>::max()), order_key<double>(std::numeric_limits<double>::lowest())};
+
+static ec_status expr_min_max_keys(const ec_dtype* dt, const void* const* p, const uint8_t* const* masks_or_null, int32_t n_streams,
+                                   const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
+                                   int64_t* keys2_dev, hipStream_t s, const char* what) {
+    ec_status st;
+    {   // the program is checked even when there is nothing to fold
+        ExprArgs probe{};
+        if ((st = program_of(probe, dt, n_streams, n_scalars, steps, n_steps, what)) != EC_OK) return st;
+    }
+    if (!keys2_dev) return set_error(EC_ERR_ARG, "%s: null keys", what);
+    // folded from (f64::MAX, f64::MIN): the identities first (a static source: the copy may still be in flight on return)
+    if ((st = check_hip(hipMemcpyAsync(keys2_dev, kF64Identities, sizeof kF64Identities, hipMemcpyHostToDevice, s), "hipMemcpyAsync(keys)")) != EC_OK) return st;
+    if (n == 0) return EC_OK;
+    ExprArgs ea{};
+    bool aligned = true;
+    int cls[kExprMaxStreams] = {0, 0, 0, 0};
+    if ((st = prepare_expr(ea, &aligned, cls, dt, p, n_streams, masks_or_null, scalars, n_scalars, steps, n_steps, n, what)) != EC_OK) return st;
+    if (aligned) {
+        bool compiled = false;
+        if ((st = expr_jit_launch(ea, n, nullptr, nullptr, keys2_dev, s, &compiled)) != EC_OK) return st;
+        if (compiled) return EC_OK;
+    }
+    // two passes: the program into a temporary from the pool, ec_min_max_keys of it (which overwrites the identities), the
+    // temporary returned in stream order
+    void *tmp = nullptr, *tmask = nullptr;
+    if ((st = ec_alloc_async(&tmp, n * sizeof(double), s)) != EC_OK) return st;
+    if (masks_or_null && (st = ec_alloc_async(&tmask, n, s)) != EC_OK) {
+        (void)ec_free_async(tmp, s);
+        return st;
+    }
+    st = launch_expr(dt, p, n_streams, masks_or_null, scalars, n_scalars, steps, n_steps, n, static_cast<double*>(tmp), static_cast<uint8_t*>(tmask), s, what);
+    if (st == EC_OK) st = ec_min_max_keys(EC_F64, tmp, static_cast<const uint8_t*>(tmask), n, keys2_dev, s);
+    const std::string keep = st != EC_OK ? last_error_text() : std::string();
+    (void)ec_free_async(tmp, s);
+    if (tmask) (void)ec_free_async(tmask, s);
+    return st != EC_OK ? set_error_text(st, keep) : EC_OK;
+}
+
+extern "C" ec_status ec_expr_min_max_keys(const ec_dtype* dt, const void* const* p, const uint8_t* const* masks_or_null, int32_t n_streams,
+                                          const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
+                                          int64_t* keys2_dev, ec_stream stream) {
+    ec_status st = ensure_ready();
+    if (st != EC_OK) return st;
+    return expr_min_max_keys(dt, p, masks_or_null, n_streams, scalars, n_scalars, steps, n_steps, n, keys2_dev, static_cast<hipStream_t>(stream),
+                             "ec_expr_min_max_keys");
+}
+
+// BufferOps::min_max (src/buffer.rs:169-173; masked: src/masked/masked_buffer.rs:208-217) of a program's result without its
+// raster.  Compiled form: the generated kernel folds order keys of the values it computes (ec_expr_jit.hip, reduce variant) —
+// the streams are read, nothing is written but 16 bytes.  Until a program is compiled (and with expr_jit = 0): two passes.
 extern "C" ec_status ec_expr_min_max(const ec_dtype* dt, const void* const* p, const uint8_t* const* masks_or_null, int32_t n_streams,
                                      const ec_value* scalars, int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, size_t n,
                                      ec_value* mn, ec_value* mx, ec_stream stream) {
@@ -199,46 +252,21 @@ extern "C" ec_status ec_expr_min_max(const ec_dtype* dt, const void* const* p, c
     if (st != EC_OK) return st;
     if (!mn || !mx) return set_error(EC_ERR_ARG, "ec_expr_min_max: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    ExprArgs ea{};
-    bool aligned = true;
-    int cls[kExprMaxStreams] = {0, 0, 0, 0};
-    {   // the program is checked even when there is nothing to fold
-        ExprArgs probe{};
-        if ((st = program_of(probe, dt, n_streams, n_scalars, steps, n_steps, "ec_expr_min_max")) != EC_OK) return st;
-    }
-    int64_t keys[2] = {~order_key<double>(std::numeric_limits<double>::max()), order_key<double>(std::numeric_limits<double>::lowest())};  // folded from (f64::MAX, f64::MIN)
-    if (n == 0) return ec_min_max_decode(EC_F64, keys, mn, mx);
-    if ((st = prepare_expr(ea, &aligned, cls, dt, p, n_streams, masks_or_null, scalars, n_scalars, steps, n_steps, n, "ec_expr_min_max")) != EC_OK) return st;
-    if (aligned && tuning().expr_jit.load() != 0) {
-        // the two key words live in the stream's reduction scratch (device memory: the kernel folds into them with atomics).
-        // (Not a 16-byte block from the pool: hipMallocAsync carves such a block out of the 2 GiB one the two-pass form has
-        // just returned, and the next 2 GiB request becomes a fresh 130 ms allocation — profiles/r03/expr_kernel.md.)
-        Scratch sc;
-        if ((st = get_scratch(s, &sc)) != EC_OK) return st;
+    // the two key words live in the stream's reduction scratch, after the words ec_min_max_keys itself uses.  (Not a 16-byte
+    // block from the pool: hipMallocAsync carves such a block out of the 2 GiB one the two-pass form has just returned, and the
+    // next 2 GiB request becomes a fresh 130 ms allocation — profiles/r03/expr_kernel.md.)
+    Scratch sc;
+    if ((st = get_scratch(s, &sc)) != EC_OK) return st;
+    int64_t keys[2];
+    {
         std::lock_guard<std::mutex> turn(*sc.mu);
-        int64_t* dkeys = sc.dev_result();
-        st = check_hip(hipMemcpyAsync(dkeys, keys, sizeof keys, hipMemcpyHostToDevice, s), "hipMemcpyAsync(keys)");
-        bool compiled = false;
-        if (st == EC_OK) st = expr_jit_launch(ea, n, nullptr, nullptr, dkeys, s, &compiled);
-        if (st == EC_OK && compiled) st = check_hip(hipMemcpyAsync(keys, dkeys, sizeof keys, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(keys)");
+        int64_t* dkeys = sc.dev_result() + 2;
+        st = expr_min_max_keys(dt, p, masks_or_null, n_streams, scalars, n_scalars, steps, n_steps, n, dkeys, s, "ec_expr_min_max");
+        if (st == EC_OK) st = check_hip(hipMemcpyAsync(keys, dkeys, sizeof keys, hipMemcpyDeviceToHost, s), "hipMemcpyAsync(keys)");
         if (st == EC_OK) st = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");  // `keys` is this frame's: nothing may be in flight on return
-        if (st != EC_OK) return st;
-        if (compiled) return ec_min_max_decode(EC_F64, keys, mn, mx);
     }
-    // two passes
-    void *tmp = nullptr, *tmask = nullptr;
-    if ((st = ec_alloc_async(&tmp, n * sizeof(double), s)) != EC_OK) return st;
-    if (masks_or_null && (st = ec_alloc_async(&tmask, n, s)) != EC_OK) {
-        (void)ec_free_async(tmp, s);
-        return st;
-    }
-    st = launch_expr(dt, p, n_streams, masks_or_null, scalars, n_scalars, steps, n_steps, n, static_cast<double*>(tmp),
-                     static_cast<uint8_t*>(tmask), s, "ec_expr_min_max");
-    if (st == EC_OK) st = ec_min_max(EC_F64, tmp, static_cast<const uint8_t*>(tmask), n, mn, mx, stream);
-    const std::string keep = st != EC_OK ? last_error_text() : std::string();
-    (void)ec_free_async(tmp, s);
-    if (tmask) (void)ec_free_async(tmask, s);
-    return st != EC_OK ? set_error_text(st, keep) : EC_OK;
+    if (st != EC_OK) return st;
+    return ec_min_max_decode(EC_F64, keys, mn, mx);
 }
 
 // Diagnostics, no device needed: the source the library would compile for this program (all streams non-temporal), and a

@@ -685,6 +685,50 @@ extern "C" ec_status ec_sharded_min_max(ec_shard_group* g, ec_dtype t, const voi
     return ec_min_max_decode(t, keys, mn, mx);
 }
 
+// min_max of an expression program's result over the whole sharded raster, without the raster: ec_expr_min_max_keys per shard
+// (the compiled reduce kernel, or two passes until the program is compiled), then the same 16-byte MAX exchange as
+// ec_sharded_min_max.  Synchronous, phased like the other reductions.
+extern "C" ec_status ec_sharded_expr_min_max(ec_shard_group* g, const ec_dtype* dt, const void* const* const* p,
+                                             const uint8_t* const* const* masks_or_null, int32_t n_streams, const ec_value* scalars,
+                                             int32_t n_scalars, const ec_expr_step* steps, int32_t n_steps, const size_t* n, ec_value* mn,
+                                             ec_value* mx) {
+    ec_status st = check_group(g, "ec_sharded_expr_min_max");
+    if (st != EC_OK) return st;
+    if (!dt || !p || !steps || !n || !mn || !mx || (n_scalars > 0 && !scalars)) return set_error(EC_ERR_ARG, "ec_sharded_expr_min_max: null argument");
+    {   // the program, once, on the calling thread
+        size_t len = 0;
+        if ((st = ec_expr_source(dt, n_streams, n_scalars, steps, n_steps, nullptr, nullptr, 0, &len)) != EC_OK) return st;
+    }
+    for (int k = 0; k < n_streams; ++k) {
+        if (!p[k] || (masks_or_null && !masks_or_null[k])) return set_error(EC_ERR_ARG, "ec_sharded_expr_min_max: stream %d has no pointer array", k);
+        if ((st = check_shard_ptrs(g, "ec_sharded_expr_min_max", "p[k]", p[k], n)) != EC_OK) return st;
+        if (masks_or_null && (st = check_shard_ptrs(g, "ec_sharded_expr_min_max", "masks[k]", reinterpret_cast<const void* const*>(masks_or_null[k]), n)) != EC_OK) return st;
+    }
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    st = for_each_shard(g, [&](int i) {
+        const void* pi[4] = {nullptr, nullptr, nullptr, nullptr};
+        const uint8_t* mi[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int k = 0; k < n_streams; ++k) {
+            pi[k] = p[k][i];
+            if (masks_or_null) mi[k] = masks_or_null[k][i];
+        }
+        return ec_expr_min_max_keys(dt, pi, masks_or_null ? mi : nullptr, n_streams, scalars, n_scalars, steps, n_steps, n[i], g->payload_dev[i], g->streams[i]);
+    });
+    const std::string keep = last_error_text();
+    const ec_status deferred = take_deferred(g);
+    if (deferred != EC_OK) return deferred;
+    if (st != EC_OK) return set_error_text(st, keep);
+    st = exchange(g, true);
+    if (st != EC_OK) return st;
+    int64_t keys[2] = {g->payload_host[0][0], g->payload_host[0][1]};
+    if (g->comms.empty())
+        for (int i = 1; i < g->n; ++i) {
+            if (g->payload_host[i][0] > keys[0]) keys[0] = g->payload_host[i][0];
+            if (g->payload_host[i][1] > keys[1]) keys[1] = g->payload_host[i][1];
+        }
+    return ec_min_max_decode(EC_F64, keys, mn, mx);
+}
+
 extern "C" ec_status ec_sharded_counts(ec_shard_group* g, const uint8_t* const* masks, const size_t* n, uint64_t* n_true,
                                        uint64_t* n_false) {
     ec_status st = check_group(g, "ec_sharded_counts");

@@ -89,6 +89,8 @@ SIGNATURES = {
     "ec_masked_fused": (I32, [I32, I32, I32, C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(VP), PV, SZ, VP, U8P, VP]),
     "ec_expr": (I32, [C.POINTER(C.c_uint8), C.POINTER(VP), I32, PV, I32, C.POINTER(EcExprStep), I32, SZ, VP, VP]),
     "ec_expr_min_max": (I32, [C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(VP), I32, PV, I32, C.POINTER(EcExprStep), I32, SZ, PV, PV, VP]),
+    "ec_expr_min_max_keys": (I32, [C.POINTER(C.c_uint8), C.POINTER(VP), C.POINTER(VP), I32, PV, I32, C.POINTER(EcExprStep), I32, SZ, VP, VP]),
+    "ec_sharded_expr_min_max": (I32, [VP, C.POINTER(C.c_uint8), C.POINTER(PVP), C.POINTER(PVP), I32, PV, I32, C.POINTER(EcExprStep), I32, PSZ, PV, PV]),
     "ec_expr_source": (I32, [C.POINTER(C.c_uint8), I32, I32, C.POINTER(EcExprStep), I32, C.c_char_p, C.c_char_p, SZ, C.POINTER(SZ)]),
     "ec_host_alloc": (I32, [PVP, SZ]),
     "ec_host_free": (I32, [VP]),

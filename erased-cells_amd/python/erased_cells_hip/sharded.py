@@ -212,6 +212,22 @@ class ShardGroup:
                                     om.ptrs if om is not None else None))
         return out if om is None else (out, om)
 
+    def program_min_max(self, streams, scalars, steps, masks=None):
+        """`(min, max)` of a program's result over the whole sharded raster without the raster (`ec_sharded_expr_min_max`)."""
+        from ._ffi import EcExprStep, PVP
+        lens = streams[0].lens
+        assert all(b.lens == lens for b in streams), "operands must be sharded identically"
+        k = len(streams)
+        dt = (C.c_uint8 * k)(*[b.ct for b in streams])
+        p = (PVP * k)(*[C.cast(b.ptrs, PVP) for b in streams])
+        m = (PVP * k)(*[C.cast(b.ptrs, PVP) for b in masks]) if masks is not None else None
+        sc = (EcValue * max(1, len(scalars)))(*[B.CellValue.new(x).to_ec() for x in scalars])
+        st = (EcExprStep * len(steps))(*[EcExprStep(*q) for q in steps])
+        mn, mx = EcValue(), EcValue()
+        check(lib().ec_sharded_expr_min_max(self.handle, dt, p, m, k, sc, len(scalars), st, len(steps), (C.c_size_t * self.n)(*lens),
+                                            C.byref(mn), C.byref(mx)))
+        return B.CellValue.from_ec(mn), B.CellValue.from_ec(mx)
+
     def program_host(self, arrays, scalars, steps, rows: int, cols: int, nodata=None, out_nodata=None, want_mask=False, chunk_cells: int = 0):
         """`fused.program_host` / `program_host_masked` over all the GPUs of the group: the row-blocks of the host arrays
         (rows x cols cells each) stream through their own device's PCIe link side by side (`ec_sharded_host_expr`)."""

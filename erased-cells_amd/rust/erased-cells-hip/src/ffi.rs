@@ -146,6 +146,12 @@ extern "C" {
     pub fn ec_expr_min_max(dt: *const ec_dtype, p: *const *const c_void, masks_or_null: *const *const u8, n_streams: i32,
                            scalars: *const ec_value, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32, n: usize,
                            mn: *mut ec_value, mx: *mut ec_value, s: ec_stream) -> ec_status;
+    pub fn ec_expr_min_max_keys(dt: *const ec_dtype, p: *const *const c_void, masks_or_null: *const *const u8, n_streams: i32,
+                                scalars: *const ec_value, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32, n: usize,
+                                keys2_dev: *mut i64, s: ec_stream) -> ec_status;
+    pub fn ec_sharded_expr_min_max(g: *mut ec_shard_group, dt: *const ec_dtype, p: *const *const *const c_void,
+                                   masks_or_null: *const *const *const u8, n_streams: i32, scalars: *const ec_value, n_scalars: i32,
+                                   steps: *const ec_expr_step, n_steps: i32, n: *const usize, mn: *mut ec_value, mx: *mut ec_value) -> ec_status;
     pub fn ec_expr_source(dt: *const ec_dtype, n_streams: i32, n_scalars: i32, steps: *const ec_expr_step, n_steps: i32,
                           arch_or_null: *const c_char, buf: *mut c_char, cap: usize, len: *mut usize) -> ec_status;
     pub fn ec_host_alloc(hptr: *mut *mut c_void, bytes: usize) -> ec_status;

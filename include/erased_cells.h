@@ -231,6 +231,12 @@ ec_status ec_masked_expr(const ec_dtype *dt, const void *const *p, const uint8_t
 ec_status ec_expr_min_max(const ec_dtype *dt, const void *const *p, const uint8_t *const *masks_or_null, int32_t n_streams,
                           const ec_value *scalars, int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps,
                           size_t n, ec_value *mn, ec_value *mx, ec_stream stream);
+/* Asynchronous: {~key(min), key(max)} of the same into DEVICE memory keys2_dev, as ec_min_max_keys writes them for a
+ * buffer — the 16-byte payload one element-wise MAX all-reduce combines across shards; decode with
+ * ec_min_max_decode(EC_F64, ...). */
+ec_status ec_expr_min_max_keys(const ec_dtype *dt, const void *const *p, const uint8_t *const *masks_or_null,
+                               int32_t n_streams, const ec_value *scalars, int32_t n_scalars, const ec_expr_step *steps,
+                               int32_t n_steps, size_t n, int64_t *keys2_dev, ec_stream stream);
 
 /* How ec_expr runs a program.  The kernel that serves every program is an interpreter (a step is decoded once per wave):
  * bound by instruction issue, ≈ 0.04 ms per step over 16384^2 cells beyond the first.  A program is launch-uniform, so
@@ -397,6 +403,13 @@ ec_status ec_sharded_host_expr(ec_shard_group *g, const ec_dtype *dt, const void
  * Synchronous result. */
 ec_status ec_sharded_min_max(ec_shard_group *g, ec_dtype t, const void *const *p, const uint8_t *const *masks_or_null,
                              const size_t *n, ec_value *mn, ec_value *mx);
+/* min_max of an expression program's result over the whole sharded raster, without the raster: ec_expr_min_max_keys per
+ * shard, one all-reduce(MAX) of the 16-byte keys, decode (Float64).  masks_or_null[k]: stream k's per-shard masks.
+ * Synchronous result. */
+ec_status ec_sharded_expr_min_max(ec_shard_group *g, const ec_dtype *dt, const void *const *const *p,
+                                  const uint8_t *const *const *masks_or_null, int32_t n_streams, const ec_value *scalars,
+                                  int32_t n_scalars, const ec_expr_step *steps, int32_t n_steps, const size_t *n,
+                                  ec_value *mn, ec_value *mx);
 /* Mask::counts (src/masked/mask.rs:72-80) of the whole raster: per-shard counts, all-reduce(SUM). Synchronous result. */
 ec_status ec_sharded_counts(ec_shard_group *g, const uint8_t *const *masks, const size_t *n,
                             uint64_t *n_true, uint64_t *n_false);

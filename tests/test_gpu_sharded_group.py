@@ -513,6 +513,19 @@ def test_config5_ndvi_in_one_process_over_a_shard_group(ec, golden_dir, G):
         assert np.array_equal(g.gather(via_mirror).view(np.uint64), exp.view(np.uint64)) and g.counts(via_mirror_mask) == (31430, 4)
         via_mirror.free()
         via_mirror_mask.free()
+        # statistics of the program over the whole raster without the raster: per-shard keys, one exchange — interpreted (two
+        # passes per shard) and compiled (the reduce kernel), plain and masked; the masked answer is the reference's NDVI-like one
+        whole = ec.fused.program([ec.CellBuffer.from_vec(nh), ec.CellBuffer.from_vec(rf)], [2.5, 6.0, 1.0], prog).min_max()
+        for mode in (0, 2):
+            chk(L.ec_tune_set(b"expr_jit", mode))
+            try:
+                mn_, mx_ = g.program_min_max([nir, red_f], [2.5, 6.0, 1.0], prog)
+                assert (mn_.bits(), mx_.bits()) == (whole[0].bits(), whole[1].bits())
+                mn_m, mx_m = g.program_min_max([nir, red_f], [2.5, 6.0, 1.0], prog, masks=[nir_m2, red_m2])
+                valid_h = (nh != 0) & (red_h.ravel() != 0)
+                assert float(mn_m.value) == float(exp[valid_h].min()) and float(mx_m.value) == float(exp[valid_h].max())
+            finally:
+                chk(L.ec_tune_set(b"expr_jit", 1))
         # the compiled form from the group's launch threads at once (expr_jit = 2: the first thread to arrive compiles, the
         # others wait for it; one module load per device)
         chk(L.ec_tune_set(b"expr_jit", 2))
