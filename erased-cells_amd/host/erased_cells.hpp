@@ -1024,6 +1024,16 @@ public:
     template <typename T, typename = decltype(CellEncoding<T>::cell_type())>
     Expr(T v) : Expr(CellValue(v)) {}
     B eval() const { return run(*n_); }
+    // (min, max) of the tree's result without its raster when the tree fits one expression program (ec_expr_min_max);
+    // otherwise eval().min_max()
+    std::pair<CellValue, CellValue> min_max() const {
+        if (n_->op != EC_OP_NONE) {
+            Compiler c;
+            c.emit(*n_);
+            if (!c.overflow && !c.streams.empty()) return program_min_max(c.streams, c.scalars, c.steps);
+        }
+        return eval().min_max();
+    }
 #define EC_EXPR_OP(SYM, OPC)                                                                             \
     friend Expr operator SYM(const Expr& a, const Expr& b) { return node(OPC, a, b); }                   \
     friend Expr operator SYM(const Expr& a, const B& b) { return node(OPC, a, Expr(b)); }                \

@@ -440,6 +440,7 @@ static void gdal_tests(const std::string& data_dir) {
         }
         CHECK(program_min_max(std::vector<const CellBuffer*>{&nir, &red, &r32}, k, evi) == evi_eager.min_max());       // statistics without the raster
         CHECK(program_min_max(std::vector<const MaskedCellBuffer*>{&mnir, &mred, &mr32}, k, evi) == mevi.min_max());
+        CHECK(((tree(nir) - red) / (tree(nir) + red)).min_max() == ((nir - red) / (nir + red)).min_max());  // NDVI's statistics, no raster
         // the same tree in operator syntax: scheduled onto the program's registers, one launch
         CHECK(((tree(nir) - red) * 2.5 / (tree(nir) + tree(red) * 6.0 - tree(r32) * 7.5 + 1.0)).eval() == evi_eager);
         CHECK((((tree(mnir) - mred) * 2.5) / (((tree(mnir) + tree(mred) * 6.0) - tree(mr32) * 7.5) + 1.0)).eval() == mevi);

@@ -318,6 +318,15 @@ class Lazy:
     def _has_buffer(self) -> bool:
         return _is_buf(self.leaf) if self.op is None else (self.l._has_buffer() or self.r._has_buffer())
 
+    def min_max(self):
+        """`(min, max)` of the tree's result without its raster when the tree fits one expression program (`program_min_max`);
+        otherwise `eval().min_max()`."""
+        if self.op is not None and self._has_buffer():
+            prog = _Compiler().compile(self)
+            if prog is not None and prog[0]:
+                return program_min_max(*prog)
+        return self.eval().min_max()
+
     def eval(self):
         if self.op is None:
             return self.leaf

@@ -913,6 +913,14 @@ def test_expr_min_max_without_the_raster(ec, pool):
         with P.jit(mode):
             mn, mx = P.program_min_max([x], [2.0], [(eco.MUL, S(0), K(0), 0)])
         assert float(mn.value) == np.finfo(np.float64).max and float(mx.value) == np.finfo(np.float64).min
+    # operator syntax: lazy(...).min_max() is the same call when the tree fits one program
+    a_, b_ = dev[eco.U16].shard(0, N), dev[eco.I16].shard(2, N)
+    t = (P.lazy(a_) - b_) * 0.5 / (P.lazy(a_) + b_ + 3.0)
+    w0, w1 = t.eval().min_max()
+    for mode in (0, 2):
+        with P.jit(mode):
+            g0, g1 = t.min_max()
+        assert (g0.bits(), g1.bits()) == (w0.bits(), w1.bits())
     # against the oracle on one case
     h0, h1 = host[eco.U16][:N], host[eco.U16][1:N + 1]
     vals = eco.f_binop(eco.DIV, eco.f_binop(eco.SUB, h0, h1), eco.f_binop(eco.ADD, h0, h1))
