@@ -251,7 +251,8 @@ ec_status ec_expr_min_max_keys(const ec_dtype *dt, const void *const *p, const u
  *
  * ec_expr_source (diagnostics; needs no device): the HIP source the library would compile for the program (every stream
  * non-temporal) into buf[0..cap), *len = bytes needed with the terminating 0; with `arch_or_null` (e.g. "gfx950") also
- * a trial compile, EC_ERR_HIP and the compiler's log in ec_last_error_string() if it fails. */
+ * a trial compile, EC_ERR_HIP and the compiler's log in ec_last_error_string() if it fails.  (With the environment
+ * variable EC_EXPR_SOURCE_VARIANT=reduce: the variant ec_expr_min_max compiles.) */
 ec_status ec_expr_source(const ec_dtype *dt, int32_t n_streams, int32_t n_scalars, const ec_expr_step *steps,
                          int32_t n_steps, const char *arch_or_null, char *buf, size_t cap, size_t *len);
 
