@@ -102,3 +102,18 @@ def test_generated_kernel_keeps_the_load_policy_in_the_machine_code(tmp_path):
     assert all(l.endswith(" nt") for l in mem), [l for l in mem if not l.endswith(" nt")]
     assert any("global_load_ushort" in l for l in mem), "a pair of 1-byte cells is one 16-bit word"
     assert "scratch_" not in body and re.search(r"\.amdhsa_private_segment_fixed_size 0\b", text)
+
+
+@pytest.mark.skipif(not HAVE_HIPRTC, reason="libhiprtc is not installed here")
+@pytest.mark.timeout(300)
+def test_reduce_variant_compiles_and_stores_nothing_but_its_keys(monkeypatch):
+    """The variant `ec_expr_min_max` compiles (EC_EXPR_SOURCE_VARIANT=reduce): hiprtc accepts it; it loads the streams, folds order
+    keys and ends in two atomic max — no store of cells; NDVI over u16 bands uses the short exact divide and no NaN tests."""
+    monkeypatch.setenv("EC_EXPR_SOURCE_VARIANT", "reduce")
+    src = ec.fused.program_source([ec.UInt16, ec.Int8, ec.Float64], 4, EVI, arch="gfx950")
+    assert src.count("__hip_atomic_fetch_max(keys2") == 2 and "__builtin_nontemporal_store" not in src
+    assert "for (unsigned long tile = blockIdx.x; tile < ntiles; tile += gridDim.x)" in src  # every wave reaches the end of its loop
+    ndvi = [(ec.SUB, S(0), S(1), 0), (ec.ADD, S(0), S(1), 1), (ec.DIV, R(0), R(1), 0)]
+    src = ec.fused.program_source([ec.UInt16, ec.UInt16], 0, ndvi, arch="gfx950")
+    body = src[src.index("static __device__ __forceinline__ void run("):src.index("static __device__ __forceinline__ long long okey")]
+    assert "= divs(r0[i], r1[i]);" in body and "NANFIX(" not in body
