@@ -119,6 +119,12 @@ struct Pipe {
     hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     void* stage[2] = {nullptr, nullptr};
+    bool simple = false;  // one chunk on the calling thread's own stream (hipStreamPerThread): no streams or events to create
+    ec_status open_simple(size_t stage_bytes) {
+        simple = true;
+        s_in = s_cmp = s_out = hipStreamPerThread;
+        return ec_alloc_async(&stage[0], stage_bytes, s_cmp);  // used in stream order on the same stream
+    }
     ec_status open(size_t stage_bytes) {
         for (hipStream_t* s : {&s_in, &s_cmp, &s_out}) {
             ec_status st = check_hip(hipStreamCreateWithFlags(s, hipStreamNonBlocking), "hipStreamCreateWithFlags");
@@ -137,6 +143,11 @@ struct Pipe {
         return check_hip(hipStreamSynchronize(s_cmp), "hipStreamSynchronize");  // the blocks exist before the copy streams touch them
     }
     ~Pipe() {
+        if (simple) {
+            (void)hipStreamSynchronize(s_cmp);
+            if (stage[0]) (void)ec_free_async(stage[0], s_cmp);
+            return;
+        }
         for (hipStream_t s : {s_in, s_out, s_cmp})
             if (s) (void)hipStreamSynchronize(s);
         for (int k = 0; k < 2; ++k)
@@ -178,7 +189,13 @@ static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void*
     if (!p_host || !out_host) return set_error(EC_ERR_ARG, "%s: null pointer", what);
     for (int k = 0; k < n_streams; ++k)
         if (!p_host[k]) return set_error(EC_ERR_ARG, "%s: stream %d is null", what, k);
-    const size_t chunk = std::min(n, chunk_cells ? chunk_cells : size_t(1) << 25);
+    // A small call is not worth a pipeline: three streams, six events, two staging slots and the page-locking of the caller's
+    // buffers cost ≈ 1.1 ms (profiles/r03/host_pipeline.md) — more than they save below ≈ 64 MiB over the link.  Such a call runs as
+    // one chunk on the calling thread's own stream, its (pageable) buffers copied by the runtime.
+    size_t link_bytes = n * sizeof(double) + (out_mask_host ? n : 0);
+    for (int k = 0; k < n_streams; ++k) link_bytes += n * ecl::size_of(dt[k]);
+    const bool small = chunk_cells == 0 && link_bytes <= (size_t(64) << 20);
+    const size_t chunk = small ? n : std::min(n, chunk_cells ? chunk_cells : size_t(1) << 25);
     // one staging slot: the operands' chunks, the f64 result (and, masked: the streams' masks, the result's mask, the selected
     // result), each on a 256-byte boundary
     size_t off[4], off_out, off_mask[4] = {0, 0, 0, 0}, off_omask = 0, off_sel = 0, bytes_per_cell[4] = {0, 0, 0, 0}, at = 0;
@@ -200,7 +217,7 @@ static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void*
         at = align_up(at + chunk * sizeof(double), 256);
     }
     PinSet pins;
-    {
+    if (!small) {
         std::vector<std::pair<const void*, size_t>> ranges;
         for (int k = 0; k < n_streams; ++k) ranges.emplace_back(p_host[k], n * bytes_per_cell[k]);
         ranges.emplace_back(out_host, n * sizeof(double));
@@ -208,7 +225,7 @@ static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void*
         pins.pin_all(ranges);
     }
     Pipe pipe;
-    if ((st = pipe.open(at)) != EC_OK) return st;
+    if ((st = small ? pipe.open_simple(at) : pipe.open(at)) != EC_OK) return st;
     ec_value sel{};
     if (out_nodata) {
         sel.dtype = EC_F64;
@@ -220,7 +237,7 @@ static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void*
         const size_t lo = c * chunk, m = std::min(chunk, n - lo);
         char* slot = static_cast<char*>(pipe.stage[k]);
         // upload: once the kernel that last read this slot's operands has finished
-        st = check_hip(hipStreamWaitEvent(pipe.s_in, pipe.ev_cmp[k], 0), "hipStreamWaitEvent");
+        if (!pipe.simple) st = check_hip(hipStreamWaitEvent(pipe.s_in, pipe.ev_cmp[k], 0), "hipStreamWaitEvent");
         const void* dptr[4] = {nullptr, nullptr, nullptr, nullptr};
         const uint8_t* dmask[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int j = 0; j < n_streams && st == EC_OK; ++j) {
@@ -228,10 +245,10 @@ static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void*
             st = check_hip(hipMemcpyAsync(slot + off[j], static_cast<const char*>(p_host[j]) + lo * bytes_per_cell[j], m * bytes_per_cell[j],
                                           hipMemcpyHostToDevice, pipe.s_in), "hipMemcpyAsync(H2D)");
         }
-        if (st == EC_OK) st = check_hip(hipEventRecord(pipe.ev_in[k], pipe.s_in), "hipEventRecord");
+        if (st == EC_OK && !pipe.simple) st = check_hip(hipEventRecord(pipe.ev_in[k], pipe.s_in), "hipEventRecord");
         // compute: once the operands are there and the slot's previous result has left for the host
-        if (st == EC_OK) st = check_hip(hipStreamWaitEvent(pipe.s_cmp, pipe.ev_in[k], 0), "hipStreamWaitEvent");
-        if (st == EC_OK) st = check_hip(hipStreamWaitEvent(pipe.s_cmp, pipe.ev_out[k], 0), "hipStreamWaitEvent");
+        if (st == EC_OK && !pipe.simple) st = check_hip(hipStreamWaitEvent(pipe.s_cmp, pipe.ev_in[k], 0), "hipStreamWaitEvent");
+        if (st == EC_OK && !pipe.simple) st = check_hip(hipStreamWaitEvent(pipe.s_cmp, pipe.ev_out[k], 0), "hipStreamWaitEvent");
         double* dout = reinterpret_cast<double*>(slot + off_out);
         const double* result = dout;
         uint8_t* domask = reinterpret_cast<uint8_t*>(slot + off_omask);
@@ -250,18 +267,19 @@ static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void*
                 result = dsel;
             }
         }
-        if (st == EC_OK) st = check_hip(hipEventRecord(pipe.ev_cmp[k], pipe.s_cmp), "hipEventRecord");
+        if (st == EC_OK && !pipe.simple) st = check_hip(hipEventRecord(pipe.ev_cmp[k], pipe.s_cmp), "hipEventRecord");
         // download
-        if (st == EC_OK) st = check_hip(hipStreamWaitEvent(pipe.s_out, pipe.ev_cmp[k], 0), "hipStreamWaitEvent");
+        if (st == EC_OK && !pipe.simple) st = check_hip(hipStreamWaitEvent(pipe.s_out, pipe.ev_cmp[k], 0), "hipStreamWaitEvent");
         if (st == EC_OK) st = check_hip(hipMemcpyAsync(out_host + lo, result, m * sizeof(double), hipMemcpyDeviceToHost, pipe.s_out), "hipMemcpyAsync(D2H)");
         if (st == EC_OK && masked && out_mask_host)
             st = check_hip(hipMemcpyAsync(out_mask_host + lo, domask, m, hipMemcpyDeviceToHost, pipe.s_out), "hipMemcpyAsync(D2H mask)");
-        if (st == EC_OK) st = check_hip(hipEventRecord(pipe.ev_out[k], pipe.s_out), "hipEventRecord");
+        if (st == EC_OK && !pipe.simple) st = check_hip(hipEventRecord(pipe.ev_out[k], pipe.s_out), "hipEventRecord");
     }
     const std::string keep = st != EC_OK ? last_error_text() : std::string();
     for (hipStream_t s : {pipe.s_in, pipe.s_cmp, pipe.s_out}) {
         const ec_status w = check_hip(hipStreamSynchronize(s), "hipStreamSynchronize");
         if (st == EC_OK && w != EC_OK) st = w;
+        if (pipe.simple) break;  // one stream
     }
     if (!keep.empty()) return set_error_text(st, keep);
     return st;

@@ -266,6 +266,8 @@ ec_status ec_expr_source(const ec_dtype *dt, int32_t n_streams, int32_t n_scalar
  * they are; any other buffer is page-locked for the duration of the call (hipHostRegister: about one pass over the
  * pages) and, if that is refused, copied through the runtime's pageable path.  Operands may be windows of one array and
  * may overlap each other; out_host may be one of the f64 operands itself (same address), not a shifted window of one.
+ * A call that moves at most 64 MiB (and leaves chunk_cells 0) is not worth a pipeline (≈ 1 ms of set-up): it runs as one
+ * chunk on the calling thread's own stream (hipStreamPerThread).
  * Synchronous; uses its own streams; may be called from several host threads at once. */
 ec_status ec_host_alloc(void **hptr, size_t bytes); /* page-locked host memory */
 ec_status ec_host_free(void *hptr);
