@@ -790,7 +790,27 @@ def test_host_to_host_expression_pipeline(ec):
     assert not errors, errors
     for r in results:
         assert_f64_bits_equal(r, exp, nan_by_class_where=loose)
-    # two overlapping windows of ONE host array as two operands (registrations may not overlap: the second goes the pageable way)
+    # the same four threads over SHIFTED windows of the same arrays: their page-lock requests overlap only partly, so a thread waits
+    # for the registration of another call to go away before it makes its own (PinSet, ec_hostpipe.hpp) — no deadlock, same cells
+    big = [rand_cells(ct, n + 4000, 9200 + ct) for ct in (eco.U16, eco.I8, eco.F32)]
+    results, errors = [None] * 4, []
+
+    def shifted(k):
+        try:
+            results[k] = P.program_host([b[1000 * k:1000 * k + n] for b in big], [2.5], steps, chunk_cells=1 << 18)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=shifted, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k, r in enumerate(results):
+        e_k, l_k = _oracle_program([b[1000 * k:1000 * k + n] for b in big], [2.5], steps)
+        assert_f64_bits_equal(r, e_k, nan_by_class_where=l_k)
+    # two overlapping windows of ONE host array as two operands: their pages are merged into one registration
     base = rand_cells(eco.U16, 400000, 77)
     w0, w1 = base[:300000], base[1000:301000]
     prog = [(eco.SUB, S(0), S(1), 0), (eco.MUL, R(0), K(0), 0)]
