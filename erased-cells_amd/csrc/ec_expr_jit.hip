@@ -360,6 +360,11 @@ ec_status expr_jit_compile(const std::string& source, const std::string& arch, s
     if (arch != "gfx950") return set_error(EC_ERR_ARG, "expression compile: processor '%s' (this library targets gfx950)", arch.c_str());
     const Hiprtc* R = hiprtc();
     if (!R) return set_error_text(EC_ERR_HIP, "expression compile: " + g_rtc.load_error);
+    // one compile at a time, process-wide: the background thread, callers in expr_jit = 2 and ec_expr_source may all arrive
+    // here at once, and two concurrent hiprtc compiles of different programs took the process down ("pure virtual method
+    // called") in a soak of the round's entry points from five host threads
+    static std::mutex one_at_a_time;
+    std::lock_guard<std::mutex> lk(one_at_a_time);
     void* prog = nullptr;
     int rc = R->create(&prog, source.c_str(), "ec_expr_jit.hip", 0, nullptr, nullptr);
     if (rc != 0) return set_error(EC_ERR_HIP, "hiprtcCreateProgram: %s", R->error_string ? R->error_string(rc) : "failed");

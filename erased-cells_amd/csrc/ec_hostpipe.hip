@@ -38,19 +38,18 @@ extern "C" ec_status ec_host_free(void* hptr) { return hptr ? check_hip(hipHostF
 
 namespace {
 struct PinTable {
-    struct Entry { size_t bytes; int refs; };
+    struct Entry { size_t bytes; int refs; bool registered; };
     std::mutex mu;
     std::condition_variable cv;
-    std::map<uintptr_t, Entry> live;  // registrations made here, by (page-aligned) base address
+    std::multimap<uintptr_t, Entry> live;  // by (page-aligned) base: registrations made here, and ranges copied without one
 } g_pins;
 constexpr uintptr_t kPage = 4096;
-}  // namespace
 
-namespace ecd {
+using Interval = std::pair<uintptr_t, uintptr_t>;
 
-void PinSet::pin_all(const std::vector<std::pair<const void*, size_t>>& ranges) {
-    // whole pages, merged
-    std::vector<std::pair<uintptr_t, uintptr_t>> iv;
+// whole pages, merged
+std::vector<Interval> merged_pages(const std::vector<std::pair<const void*, size_t>>& ranges) {
+    std::vector<Interval> iv;
     for (const auto& r : ranges) {
         if (!r.first || r.second == 0) continue;
         const uintptr_t lo = reinterpret_cast<uintptr_t>(r.first) / kPage * kPage;
@@ -58,42 +57,78 @@ void PinSet::pin_all(const std::vector<std::pair<const void*, size_t>>& ranges) 
         iv.emplace_back(lo, hi);
     }
     std::sort(iv.begin(), iv.end());
-    std::vector<std::pair<uintptr_t, uintptr_t>> merged;
+    std::vector<Interval> merged;
     for (const auto& x : iv) {
         if (!merged.empty() && x.first <= merged.back().second) merged.back().second = std::max(merged.back().second, x.second);
         else merged.push_back(x);
     }
+    return merged;
+}
+
+// does any of `merged` collide with an entry of the table?  A registration collides when it overlaps without covering; a range in
+// use without a registration collides with a new REGISTRATION that overlaps it at all (two unregistered users never collide).
+bool collides(const std::vector<Interval>& merged, bool want_registration) {
+    for (const auto& m : merged)
+        for (const auto& kv : g_pins.live) {
+            const uintptr_t elo = kv.first, ehi = kv.first + kv.second.bytes;
+            if (ehi <= m.first || m.second <= elo) continue;
+            if (kv.second.registered) {
+                if (!(elo <= m.first && m.second <= ehi)) return true;
+            } else if (want_registration) {
+                return true;
+            }
+        }
+    return false;
+}
+
+// a registration in flight that covers [lo, hi)
+std::multimap<uintptr_t, PinTable::Entry>::iterator covering(const Interval& m) {
+    for (auto it = g_pins.live.begin(); it != g_pins.live.end(); ++it)
+        if (it->second.registered && it->first <= m.first && m.second <= it->first + it->second.bytes) return it;
+    return g_pins.live.end();
+}
+}  // namespace
+
+namespace ecd {
+
+void PinSet::pin_all(const std::vector<std::pair<const void*, size_t>>& ranges) {
+    const std::vector<Interval> merged = merged_pages(ranges);
     std::unique_lock<std::mutex> lk(g_pins.mu);
-    for (;;) {  // wait (holding nothing) while a range partly overlaps a registration of another call in flight
-        bool conflict = false;
-        for (const auto& m : merged)
-            for (const auto& kv : g_pins.live) {
-                const uintptr_t elo = kv.first, ehi = kv.first + kv.second.bytes;
-                if (ehi <= m.first || m.second <= elo) continue;
-                if (!(elo <= m.first && m.second <= ehi)) conflict = true;
-            }
-        if (!conflict) break;
-        g_pins.cv.wait(lk);
-    }
+    while (collides(merged, true)) g_pins.cv.wait(lk);  // holding nothing while it waits: all of a call's ranges are taken at once
     for (const auto& m : merged) {
-        bool shared = false;
-        for (auto& kv : g_pins.live)
-            if (kv.first <= m.first && m.second <= kv.first + kv.second.bytes) {  // inside a registration in flight: share it
-                ++kv.second.refs;
-                held_.push_back(kv.first);
-                shared = true;
-                break;
-            }
-        if (shared) continue;
+        auto it = covering(m);
+        if (it != g_pins.live.end()) {  // inside a registration in flight: share it
+            ++it->second.refs;
+            held_.push_back(Held{it->first, it->second.bytes, true});
+            continue;
+        }
         hipPointerAttribute_t at{};
         if (hipPointerGetAttributes(&at, reinterpret_cast<const void*>(m.first)) == hipSuccess && at.type == hipMemoryTypeHost) continue;  // the caller's own page-locked memory
         (void)hipGetLastError();  // "not a HIP pointer" is an answer, not a failure
         // page-locked for every device: a shard group copies from it on all of them
         if (hipHostRegister(reinterpret_cast<void*>(m.first), m.second - m.first, hipHostRegisterPortable) == hipSuccess) {
-            g_pins.live[m.first] = PinTable::Entry{m.second - m.first, 1};
-            held_.push_back(m.first);
+            g_pins.live.emplace(m.first, PinTable::Entry{m.second - m.first, 1, true});
+            held_.push_back(Held{m.first, m.second - m.first, true});
         } else {
-            (void)hipGetLastError();  // refused (a read-only mapping, ...): the runtime's pageable path copies such a range
+            (void)hipGetLastError();  // refused (a read-only mapping, ...): the runtime's pageable path copies such a range —
+            g_pins.live.emplace(m.first, PinTable::Entry{m.second - m.first, 1, false});  // — which makes it a range in use
+            held_.push_back(Held{m.first, m.second - m.first, false});
+        }
+    }
+}
+
+void PinSet::use_all(const std::vector<std::pair<const void*, size_t>>& ranges) {
+    const std::vector<Interval> merged = merged_pages(ranges);
+    std::unique_lock<std::mutex> lk(g_pins.mu);
+    while (collides(merged, false)) g_pins.cv.wait(lk);
+    for (const auto& m : merged) {
+        auto it = covering(m);
+        if (it != g_pins.live.end()) {
+            ++it->second.refs;
+            held_.push_back(Held{it->first, it->second.bytes, true});
+        } else {
+            g_pins.live.emplace(m.first, PinTable::Entry{m.second - m.first, 1, false});
+            held_.push_back(Held{m.first, m.second - m.first, false});
         }
     }
 }
@@ -101,11 +136,15 @@ void PinSet::pin_all(const std::vector<std::pair<const void*, size_t>>& ranges) 
 PinSet::~PinSet() {
     if (held_.empty()) return;
     std::lock_guard<std::mutex> lk(g_pins.mu);
-    for (uintptr_t base : held_) {
-        auto it = g_pins.live.find(base);
-        if (it != g_pins.live.end() && --it->second.refs == 0) {
-            (void)hipHostUnregister(reinterpret_cast<void*>(base));
-            g_pins.live.erase(it);
+    for (const Held& h : held_) {
+        auto range = g_pins.live.equal_range(h.base);
+        for (auto it = range.first; it != range.second; ++it) {
+            if (it->second.registered != h.registered || it->second.bytes != h.bytes) continue;
+            if (--it->second.refs == 0) {
+                if (h.registered) (void)hipHostUnregister(reinterpret_cast<void*>(h.base));
+                g_pins.live.erase(it);
+            }
+            break;
         }
     }
     g_pins.cv.notify_all();
@@ -217,12 +256,13 @@ static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void*
         at = align_up(at + chunk * sizeof(double), 256);
     }
     PinSet pins;
-    if (!small) {
+    {
         std::vector<std::pair<const void*, size_t>> ranges;
         for (int k = 0; k < n_streams; ++k) ranges.emplace_back(p_host[k], n * bytes_per_cell[k]);
         ranges.emplace_back(out_host, n * sizeof(double));
         if (out_mask_host) ranges.emplace_back(out_mask_host, n);
-        pins.pin_all(ranges);
+        if (small) pins.use_all(ranges);  // copied by the runtime's pageable path: no registration may come or go under the copies
+        else pins.pin_all(ranges);
     }
     Pipe pipe;
     if ((st = small ? pipe.open_simple(at) : pipe.open(at)) != EC_OK) return st;

@@ -17,11 +17,19 @@ namespace ecd {
 // inside the registration their caller made for the whole raster), and the call that finishes first does not unregister
 // pages another is still copying from.  A range that partly overlaps a registration of ANOTHER call in flight waits for
 // that call — holding nothing while it waits, all of a call's ranges are taken at once.
+//
+// A call that copies WITHOUT page-locking (the small form of ec_host_expr: the runtime's pageable path) enters its ranges too
+// (`use_all`): the HIP runtime looks a host pointer's registration up when a copy is queued, and a registration that another
+// thread makes or removes under a copy in flight took the process down ("pure virtual method called") in a soak of the round's
+// entry points from five host threads.  Ranges in use without a registration make an overlapping registration wait; a range
+// inside a registration in flight shares it.
 class PinSet {
-    std::vector<uintptr_t> held_;  // table keys this object holds a reference on
+    struct Held { uintptr_t base; size_t bytes; bool registered; };
+    std::vector<Held> held_;  // table entries this object holds a reference on
 
 public:
     void pin_all(const std::vector<std::pair<const void*, size_t>>& ranges);
+    void use_all(const std::vector<std::pair<const void*, size_t>>& ranges);
     ~PinSet();
     PinSet() = default;
     PinSet(const PinSet&) = delete;

@@ -1,0 +1,89 @@
+"""The round's new entry points from five host threads at once, for a few seconds: resident programs with the run mode changing
+(interpreted / compiled at once / compiled in the background), host-to-host calls in the one-chunk form and through the
+pipeline over the SAME numpy arrays, program statistics, and a shard group running programs and the sharded host pipeline —
+every result compared with answers computed beforehand.  This is the test that found that two hiprtc compiles must not run at
+once and that a page-lock registration must not come or go under another call's pageable copy of the same array
+(EC_SOAK_SECONDS for longer runs).
+"""
+import os
+import sys
+import threading
+import time
+import traceback
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_new_entry_points_from_five_threads_at_once():
+    import erased_cells_hip as ec
+    from erased_cells_hip import sharded
+    ec.init(0)
+    P = ec.fused
+    S, R, K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+    rng = np.random.default_rng(3)
+    n = 1 << 20
+    a = rng.integers(1, 40000, n).astype(np.uint16); b = rng.integers(1, 30000, n).astype(np.uint16); c = rng.uniform(-5, 5, n).astype(np.float32)
+    da, db, dc = (ec.CellBuffer.from_vec(x) for x in (a, b, c))
+    progs = [[(ec.SUB, S(0), S(1), 0), (ec.ADD, S(0), S(1), 1), (ec.DIV, R(0), R(1), 0)],
+             [(ec.MUL, S(0), K(0), 0), (ec.ADD, R(0), S(2), 1), (ec.DIV, R(1), S(1), 0), (ec.SUB, R(0), K(1), 2)],
+             [(ec.ADD, S(2), S(2), 0), (ec.MUL, R(0), S(0), 0)]]
+    ec.lib().ec_tune_set(b"expr_jit", 0)
+    want = [P.program([da, db, dc], [2.5, 0.25], pr).to_numpy() for pr in progs]
+    want_mm = [P.program([da, db, dc], [2.5, 0.25], pr).min_max() for pr in progs]
+    ec.lib().ec_tune_set(b"expr_jit", 1)
+    stop = time.time() + float(os.environ.get("EC_SOAK_SECONDS", "8"))
+    errors, counts = [], [0] * 6
+    def guard(k, fn):
+        def run():
+            try:
+                while time.time() < stop:
+                    fn(); counts[k] += 1
+            except BaseException as e:  # noqa: BLE001
+                errors.append((k, repr(e)))
+                print("thread", k, "failed after", counts[k], "iterations:", repr(e), flush=True)
+                traceback.print_exc()
+        return run
+    def t_resident():
+        i = counts[0] % 3
+        ec.lib().ec_tune_set(b"expr_jit", [0, 2, 1][counts[0] % 3])
+        assert np.array_equal(P.program([da, db, dc], [2.5, 0.25], progs[i]).to_numpy().view(np.uint64), want[i].view(np.uint64))
+    def t_host_small():
+        i = counts[1] % 3
+        assert np.array_equal(P.program_host([a, b, c], [2.5, 0.25], progs[i]).view(np.uint64), want[i].view(np.uint64))
+    def t_host_pipe():
+        i = counts[2] % 3
+        assert np.array_equal(P.program_host([a, b, c], [2.5, 0.25], progs[i], chunk_cells=1 << 17).view(np.uint64), want[i].view(np.uint64))
+    def t_minmax():
+        i = counts[3] % 3
+        mn, mx = P.program_min_max([da, db, dc], [2.5, 0.25], progs[i])
+        assert (mn.bits(), mx.bits()) == (want_mm[i][0].bits(), want_mm[i][1].bits())
+    g = sharded.ShardGroup([0, 0, 0], host_combine=True)
+    rows, cols = 1024, 1024
+    sa, sb, sc_ = g.scatter(a, rows, cols), g.scatter(b, rows, cols), g.scatter(c, rows, cols)
+    def t_group():
+        i = counts[4] % 3
+        out = g.program([sa, sb, sc_], [2.5, 0.25], progs[i])
+        got = g.gather(out); out.free()
+        assert np.array_equal(got.view(np.uint64), want[i].view(np.uint64))
+        mn, mx = g.program_min_max([sa, sb, sc_], [2.5, 0.25], progs[i])
+        assert (mn.bits(), mx.bits()) == (want_mm[i][0].bits(), want_mm[i][1].bits())
+    def t_group_host():
+        i = counts[5] % 3
+        got = g.program_host([a, b, c], [2.5, 0.25], progs[i], rows, cols, chunk_cells=1 << 16)
+        assert np.array_equal(got.view(np.uint64), want[i].view(np.uint64))
+    fns = [t_resident, t_host_small, t_host_pipe, t_minmax, t_group, t_group_host]
+    # the two group users share the group's call order; run them from ONE thread alternately
+    def t_groups():
+        t_group(); t_group_host()
+    threads = [threading.Thread(target=guard(k, f)) for k, f in enumerate([t_resident, t_host_small, t_host_pipe, t_minmax, t_groups])]
+    for t in threads: t.start()
+    for t in threads: t.join()
+
+
+    g.__exit__(None, None, None)
+    ec.lib().ec_tune_set(b"expr_jit", 1)
+    assert not errors, errors[:3]
+    assert all(c > 0 for c in counts[:5]), counts
