@@ -20,6 +20,7 @@
 #include <mutex>
 #include <string>
 
+#include "ec_hostpipe.hpp"
 #include "ec_runtime.hpp"
 
 namespace ecd {
@@ -389,6 +390,8 @@ extern "C" ec_status ec_pool_trim(size_t keep_bytes) {
 extern "C" ec_status ec_upload(void* dst_dev, const void* src_host, size_t bytes, ec_stream stream) {
     if (bytes == 0) return EC_OK;
     if (!dst_dev || !src_host) return set_error(EC_ERR_ARG, "ec_upload: null pointer");
+    PinSet in_use;  // no page-lock registration of this range (a host-to-host call in another thread) may come or go under the copy
+    in_use.use_all({{src_host, bytes}});
     ec_status st = check_hip(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, S(stream)), "hipMemcpyAsync(H2D)");
     if (st != EC_OK) return st;
     return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");  // src_host may be pageable
@@ -396,6 +399,8 @@ extern "C" ec_status ec_upload(void* dst_dev, const void* src_host, size_t bytes
 extern "C" ec_status ec_download(void* dst_host, const void* src_dev, size_t bytes, ec_stream stream) {
     if (bytes == 0) return EC_OK;
     if (!dst_host || !src_dev) return set_error(EC_ERR_ARG, "ec_download: null pointer");
+    PinSet in_use;  // (as in ec_upload)
+    in_use.use_all({{dst_host, bytes}});
     ec_status st = check_hip(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, S(stream)), "hipMemcpyAsync(D2H)");
     if (st != EC_OK) return st;
     return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize");

@@ -1,4 +1,4 @@
-"""The round's new entry points from five host threads at once, for a few seconds: resident programs with the run mode changing
+"""The round's new entry points from six host threads at once, for a few seconds: resident programs with the run mode changing
 (interpreted / compiled at once / compiled in the background), host-to-host calls in the one-chunk form and through the
 pipeline over the SAME numpy arrays, program statistics, and a shard group running programs and the sharded host pipeline —
 every result compared with answers computed beforehand.  This is the test that found that two hiprtc compiles must not run at
@@ -17,7 +17,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_new_entry_points_from_five_threads_at_once():
+def test_new_entry_points_from_six_threads_at_once():
     import erased_cells_hip as ec
     from erased_cells_hip import sharded
     ec.init(0)
@@ -71,14 +71,18 @@ def test_new_entry_points_from_five_threads_at_once():
         mn, mx = g.program_min_max([sa, sb, sc_], [2.5, 0.25], progs[i])
         assert (mn.bits(), mx.bits()) == (want_mm[i][0].bits(), want_mm[i][1].bits())
     def t_group_host():
-        i = counts[5] % 3
+        i = counts[4] % 3
         got = g.program_host([a, b, c], [2.5, 0.25], progs[i], rows, cols, chunk_cells=1 << 16)
+        assert np.array_equal(got.view(np.uint64), want[i].view(np.uint64))
+    def t_from_vec():  # the plain hand-over (pageable copies of the same arrays the pipelines page-lock)
+        i = counts[5] % 3
+        got = P.program([ec.CellBuffer.from_vec(a), ec.CellBuffer.from_vec(b), ec.CellBuffer.from_vec(c)], [2.5, 0.25], progs[i]).to_numpy()
         assert np.array_equal(got.view(np.uint64), want[i].view(np.uint64))
     fns = [t_resident, t_host_small, t_host_pipe, t_minmax, t_group, t_group_host]
     # the two group users share the group's call order; run them from ONE thread alternately
     def t_groups():
         t_group(); t_group_host()
-    threads = [threading.Thread(target=guard(k, f)) for k, f in enumerate([t_resident, t_host_small, t_host_pipe, t_minmax, t_groups])]
+    threads = [threading.Thread(target=guard(k, f)) for k, f in enumerate([t_resident, t_host_small, t_host_pipe, t_minmax, t_groups, t_from_vec])]
     for t in threads: t.start()
     for t in threads: t.join()
 
@@ -86,4 +90,4 @@ def test_new_entry_points_from_five_threads_at_once():
     g.__exit__(None, None, None)
     ec.lib().ec_tune_set(b"expr_jit", 1)
     assert not errors, errors[:3]
-    assert all(c > 0 for c in counts[:5]), counts
+    assert all(c > 0 for c in counts), counts
