@@ -91,3 +91,46 @@ def test_new_entry_points_from_six_threads_at_once():
     ec.lib().ec_tune_set(b"expr_jit", 1)
     assert not errors, errors[:3]
     assert all(c > 0 for c in counts), counts
+
+
+def test_resident_api_from_six_threads_sharing_the_default_stream():
+    """Operators, fused chains, masked operators, reductions (the per-stream scratch and its turn-taking), converts and device-side
+    comparisons from six host threads on the library's default stream, each thread on its own buffers, every result checked."""
+    import erased_cells_hip as ec
+    ec.init(0)
+    rng = np.random.default_rng(5)
+    n = 300001
+    stop = time.time() + float(os.environ.get("EC_SOAK_SECONDS", "6"))
+    errors, counts = [], [0] * 6
+    def worker(k):
+        try:
+            r = np.random.default_rng(100 + k)
+            a = r.integers(0, 60000, n).astype(np.uint16); b = r.integers(1, 255, n).astype(np.uint8); c = r.uniform(-9, 9, n).astype(np.float32)
+            m = r.integers(0, 2, n).astype(np.uint8)
+            da, db, dc = ec.CellBuffer.from_vec(a), ec.CellBuffer.from_vec(b), ec.CellBuffer.from_vec(c)
+            dm = ec.Mask.new(m)
+            w_div = a.astype(np.float64) / b.astype(np.float64)
+            w_chain = (a.astype(np.float64) + c.astype(np.float64)) * b.astype(np.float64)
+            while time.time() < stop:
+                q = da / db
+                assert np.array_equal(q.to_numpy(), w_div)
+                mn, mx = q.min_max()
+                assert float(mn.value) == w_div.min() and float(mx.value) == w_div.max()
+                f = ec.fused.expr(da, ec.ADD, dc, ec.MUL, db)
+                assert np.array_equal(f.to_numpy(), w_chain)
+                mq = ec.MaskedCellBuffer(da, dm) - ec.MaskedCellBuffer(db, dm)
+                assert mq.counts() == (int(m.sum()), int(n - m.sum()))
+                mmn, mmx = mq.min_max()
+                v = (a.astype(np.float64) - b.astype(np.float64))[m.astype(bool)]
+                assert float(mmn.value) == v.min() and float(mmx.value) == v.max()
+                assert (da.convert(ec.Float32) == ec.CellBuffer.from_vec(a.astype(np.float32)))
+                assert q == ec.CellBuffer.from_vec(w_div) and not (q == f)
+                counts[k] += 1
+        except BaseException as e:  # noqa: BLE001
+            errors.append((k, repr(e))); print("thread", k, "failed:", repr(e), flush=True); traceback.print_exc()
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+
+    assert not errors, errors[:3]
+    assert all(c > 0 for c in counts), counts
