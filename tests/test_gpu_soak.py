@@ -134,3 +134,43 @@ def test_resident_api_from_six_threads_sharing_the_default_stream():
 
     assert not errors, errors[:3]
     assert all(c > 0 for c in counts), counts
+
+
+def test_shard_groups_from_three_threads():
+    """Two shard groups on one device, one of them shared by two host threads: scatter, fire-and-forget operators, syncs, reductions,
+    gathers and frees interleave; every answer checked (the group keeps each thread's calls in order and whole)."""
+    import erased_cells_hip as ec
+    from erased_cells_hip import sharded
+    ec.init(0)
+    rows, cols = 640, 480
+    n = rows * cols
+    stop = time.time() + float(os.environ.get("EC_SOAK_SECONDS", "5"))
+    errors, counts = [], [0] * 3
+    gA = sharded.ShardGroup([0] * 4, host_combine=True)
+    gB = sharded.ShardGroup([0] * 3, host_combine=True)
+    def worker(k, g):
+        try:
+            r = np.random.default_rng(200 + k)
+            a = r.integers(1, 60000, n).astype(np.uint16); b = r.integers(1, 60000, n).astype(np.uint16)
+            want = a.astype(np.float64) / b.astype(np.float64)
+            while time.time() < stop:
+                sa, sb = g.scatter(a, rows, cols), g.scatter(b, rows, cols)
+                q = g.binop(ec.DIV, sa, sb)
+                mn, mx = g.min_max(q)
+                assert float(mn.value) == want.min() and float(mx.value) == want.max()
+                assert np.array_equal(g.gather(q), want)
+                s2 = g.binop(ec.SUB, q, q)
+                g.sync()
+                z0, z1 = g.min_max(s2)
+                assert float(z0.value) == 0.0 and float(z1.value) == 0.0
+                for x in (sa, sb, q, s2): x.free()
+                counts[k] += 1
+        except BaseException as e:  # noqa: BLE001
+            errors.append((k, repr(e))); print("thread", k, "failed:", repr(e), flush=True); traceback.print_exc()
+    threads = [threading.Thread(target=worker, args=(0, gA)), threading.Thread(target=worker, args=(1, gA)), threading.Thread(target=worker, args=(2, gB))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    gA.__exit__(None, None, None); gB.__exit__(None, None, None)
+
+    assert not errors, errors[:3]
+    assert all(c > 0 for c in counts), counts
