@@ -63,7 +63,9 @@ static void launch_map_u(const Fn& fn, size_t n, hipStream_t s) {
     const size_t groups = n / Fn::CPL;
     const size_t tiles = (groups + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
     const size_t stream_bytes[2] = {n * Fn::kIn0, n * Fn::kIn1};
-    k_map<Fn, U><<<grid_for(tiles), kBlock, 0, s>>>(fn, n, cache_plan(stream_bytes, 2));
+    // a launch that loads nothing (fill, the generators) is a pure write stream: unused dynamic LDS caps its resident workgroups per CU
+    const unsigned lds = (Fn::kIn0 == 0 && Fn::kIn1 == 0) ? static_cast<unsigned>(tuning().write_lds_kb.load()) << 10 : 0u;
+    k_map<Fn, U><<<grid_for(tiles), kBlock, lds, s>>>(fn, n, cache_plan(stream_bytes, 2));
 }
 
 template <typename Fn>

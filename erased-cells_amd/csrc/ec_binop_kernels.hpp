@@ -80,7 +80,11 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
             // (integer compares), and only a wave that holds a zero divisor runs the selects — 5 of the 11 vector instructions
             // per cell off the common path (with the u8 operand served from the Infinity Cache the divide is no longer fully
             // hidden behind memory: 0.4222 ms against the add's 0.4134 before this, profiles/r03/kernel_table.md)
-            double av[2 * U], bv[2 * U], q[2 * U];
+            // stage by stage over the tile's 2 U cells, not cell by cell: each quotient is a chain of six dependent FP64 instructions,
+            // and written cell by cell the compiler issues the chains one after the other (≈ 300 cycles in which the wave has no
+            // second instruction to offer: the divide ran 2 % behind the add at equal bytes, profiles/r04/bench_store_policy_ab.md);
+            // staged, the 2 U chains overlap
+            double av[2 * U], bv[2 * U], q[2 * U], y[2 * U], e[2 * U];
             bool zero = false;
 #pragma unroll
             for (int j = 0; j < U; ++j)
@@ -89,8 +93,8 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
                     av[2 * j + k] = to_f64(a[j][k]);
                     bv[2 * j + k] = to_f64(b[j][k]);
                     zero = zero || b[j][k] == 0;
-                    q[2 * j + k] = div_small_int_nonzero(av[2 * j + k], bv[2 * j + k]);
                 }
+            div_small_int_nonzero_staged<2 * U>(av, bv, q, y, e);
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(zero) != 0, 0)) {
 #pragma unroll
                 for (int i = 0; i < 2 * U; ++i) q[i] = bv[i] == 0.0 ? div_by_zero(av[i]) : q[i];
@@ -333,7 +337,7 @@ __device__ __forceinline__ void mask_and_body(const uint8_t* __restrict__ lm, co
             x = load_vec<!(B & 1u)>(a + g);
             y = load_vec<!(B & 2u)>(b + g);
         });
-        nt_store(x & y, o + g);
+        mask_store(x & y, o + g);
     }
     if (blockIdx.x == 0)
         for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) st_cell<uint8_t>(ld_cell(lm + i) & ld_cell(rm + i), om + i);

@@ -30,7 +30,7 @@ static ec_status launch_binop_pair(const void* l, const void* r, size_t n, doubl
     const unsigned head = peel_head(l, sizeof(L), r, sizeof(R), n);
     const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
     const size_t stream_bytes[2] = {n * sizeof(L), l == r ? 0 : n * sizeof(R)};  // l == r: one stream, read twice
-    unsigned policy = cache_plan(stream_bytes, 2);
+    unsigned policy = cache_plan(stream_bytes, 2, n * sizeof(double));
     if (l == r && (policy & 1u)) policy |= 2u;
     k_binop_direct<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n, head | (policy << 8));
     return check_launch("binop(direct)");
@@ -56,7 +56,7 @@ static ec_status launch_masked_pair(const void* l, const uint8_t* lm, const void
     const unsigned head = peel_head(l, sizeof(L), r, sizeof(R), n);
     const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
     const size_t stream_bytes[4] = {n * sizeof(L), l == r ? 0 : n * sizeof(R), n, lm == rm ? 0 : n};
-    unsigned policy = cache_plan(stream_bytes, 4);
+    unsigned policy = cache_plan(stream_bytes, 4, n * sizeof(double));
     if (l == r && (policy & 1u)) policy |= 2u;
     if (lm == rm && (policy & 4u)) policy |= 8u;
     k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, false><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n, head | (policy << 8));
@@ -74,7 +74,7 @@ static ec_status launch_scalar(const void* l, double rhs, size_t n, double* out,
     const unsigned head = peel_head(l, sizeof(L), nullptr, 0, n);
     const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
     const size_t stream_bytes[1] = {n * sizeof(L)};
-    const unsigned policy = cache_plan(stream_bytes, 1);
+    const unsigned policy = cache_plan(stream_bytes, 1, n * sizeof(double));
     k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rhs, out, n, head | (policy << 8));
     return check_launch("binop_scalar(direct)");
 }

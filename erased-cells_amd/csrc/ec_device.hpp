@@ -76,6 +76,22 @@ __device__ __forceinline__ double div_small_int_nonzero(double a, double b) {
     const double r = __builtin_fma(-b, q, a);
     return __builtin_fma(r, y, q);
 }
+// the same six instructions for N independent quotients, stage by stage (the N dependency chains overlap)
+template <int N>
+__device__ __forceinline__ void div_small_int_nonzero_staged(const double (&a)[N], const double (&b)[N], double (&q)[N], double (&y)[N], double (&e)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = __builtin_amdgcn_rcp(b[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-b[i], y[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = __builtin_fma(y[i], e[i], y[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = a[i] * y[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-b[i], q[i], a[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = __builtin_fma(e[i], y[i], q[i]);
+}
 // what the reference's f64 divide gives for b == 0
 __device__ __forceinline__ double div_by_zero(double a) {
     return a == 0.0 ? bits_f64(kNegQNaN) : (a > 0.0 ? __builtin_inf() : -__builtin_inf());
@@ -157,9 +173,55 @@ template <typename V>
 __device__ __forceinline__ V nt_load(const V* p) {
     return __builtin_nontemporal_load(reinterpret_cast<const typename under_aligned<V>::type*>(p));
 }
+// Streaming stores.  EC_STORE_POLICY (build-time A/B switch, like EC_NT_STORE in ec_runtime.hpp):
+//   1  `nt`      — what rounds 1-3 shipped
+//   2  `sc1 nt`  — write-through at device scope: the L2 passes each 64-byte write on as it completes instead of keeping the line
+//                  dirty and writing it back when it is evicted.  With every operand byte coming from HBM (rotating operand sets)
+//                  the 3 B-read / 8 B-write mix runs at 0.82 of the HBM peak with these against 0.78 with `nt` alone, the same
+//                  tile shape and loads (tools/tune_store.hip, profiles/r04/tune_store_v1.log, _v2.log).
+// hipcc has no source form for `sc1` on a plain store (volatile gives `sc0 sc1` on a flat store and waits for it; an atomic store
+// stops at 64 bits), so policy 2 is inline asm: one `global_store_*` by width, the address as a 64-bit VGPR pair.  `s_nop 1` behind
+// the 16-byte form: on gfx940+ a VALU write of the data registers of a store of more than 64 bits needs two wait states, and
+// the compiler's hazard recognizer does not look into asm (without it the sweep's pure-write variants stored garbage).  No memory
+// clobber: no kernel of the library reads what it stores, so the scheduler stays free to keep later loads above the store.
+//   3  `sc1 nt` for VALUE streams (the f64 results, converted cells: nt_store / st_cell), `nt` for MASK streams (mask_store): the
+//      default.  Write-through pays where the output is most of the launch's bytes and leaves the L2 in 16-byte-per-lane stores;
+//      the 1 B/cell mask outputs (mask_and, mask_not, mask_from_nodata: a third to a half of their launch's bytes) ran 1-2 % slower
+//      with it (profiles/r04/store_policy_ab.md).
+#ifndef EC_STORE_POLICY
+#define EC_STORE_POLICY 3
+#endif
+template <typename V>
+__device__ __forceinline__ void stream_store_asm(V v, V* p) {
+    static_assert(sizeof(V) == 1 || sizeof(V) == 2 || sizeof(V) == 4 || sizeof(V) == 8 || sizeof(V) == 16, "store width");
+    if constexpr (sizeof(V) == 16) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(vec<uint32_t, 4>, v)));
+    } else if constexpr (sizeof(V) == 8) {
+        asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(p), "v"(__builtin_bit_cast(vec<uint32_t, 2>, v)));
+    } else if constexpr (sizeof(V) == 4) {
+        asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(__builtin_bit_cast(uint32_t, v)));
+    } else if constexpr (sizeof(V) == 2) {
+        asm volatile("global_store_short %0, %1, off sc1 nt" ::"v"(p), "v"(uint32_t(__builtin_bit_cast(uint16_t, v))));
+    } else {
+        asm volatile("global_store_byte %0, %1, off sc1 nt" ::"v"(p), "v"(uint32_t(__builtin_bit_cast(uint8_t, v))));
+    }
+}
 template <typename V>
 __device__ __forceinline__ void nt_store(V v, V* p) {
+#if EC_STORE_POLICY >= 2
+    stream_store_asm(v, p);
+#else
     __builtin_nontemporal_store(v, reinterpret_cast<typename under_aligned<V>::type*>(p));
+#endif
+}
+// the mask output of a launch (1 byte per cell, moved as words)
+template <typename V>
+__device__ __forceinline__ void mask_store(V v, V* p) {
+#if EC_STORE_POLICY == 2
+    stream_store_asm(v, p);
+#else
+    __builtin_nontemporal_store(v, reinterpret_cast<typename under_aligned<V>::type*>(p));
+#endif
 }
 template <typename V>
 __device__ __forceinline__ V plain_load(const V* p) {
@@ -176,7 +238,13 @@ __device__ __forceinline__ void plain_store(V v, V* p) {
 template <typename T>
 __device__ __forceinline__ T ld_cell(const T* p) { return __builtin_nontemporal_load(p); }
 template <typename T>
-__device__ __forceinline__ void st_cell(T v, T* p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_cell(T v, T* p) {
+#if EC_STORE_POLICY >= 2
+    stream_store_asm(v, p);
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
 
 // N cells of type T as one lane loads them.  Cells of 2 bytes and more are the typed vector.  1-BYTE cells travel as
 // unsigned words (uint16_t, uint32_t, 2 or 4 dwords) and are picked apart with shifts: hipcc (ROCm 7.2) drops the

@@ -11,6 +11,7 @@
 #include <string>
 
 #include "ec_expr.hpp"
+#include "ec_expr_fixed.hpp"
 #include "ec_expr_jit.hpp"
 #include "ec_lattice.hpp"
 #include "ec_runtime.hpp"
@@ -25,6 +26,8 @@ int64_t expr_stat(const char* key, bool* known) {
         *known = true;
         return g_interpreted.load(std::memory_order_relaxed);
     }
+    const int64_t v = expr_fixed_stat(key, known);  // expr_fixed_launches
+    if (*known) return v;
     return expr_jit_stat(key, known);
 }
 }  // namespace ecd
@@ -125,7 +128,7 @@ static ec_status prepare_expr(ExprArgs& ea, bool* aligned_out, int* cls, const e
     }
     for (int j = 0; j < ea.nmask; ++j) stream_bytes[4 + j] = n;
     ea.head = (n >= 2 && tuning().peel && c1 < c0) ? 1 : 0;
-    unsigned policy = cache_plan(stream_bytes, 8);
+    unsigned policy = cache_plan(stream_bytes, 8, n * sizeof(double));
     for (int k = 1; k < n_streams; ++k)
         for (int j = 0; j < k; ++j)
             if (p[j] == p[k]) policy = (policy & ~(1u << k)) | (((policy >> j) & 1u) << k);  // one buffer, one policy
@@ -149,6 +152,12 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
         k_expr_cellwise<0><<<grid_capped((n + kBlock - 1) / kBlock, 8), kBlock, 0, s>>>(ea, out, out_mask, n);
         return check_launch("expr(cellwise)");
     }
+    // A program of the ahead-of-time catalogue (ec_expr_fixed.hpp: NDVI, (a + b) * c, EVI, a * k0 + k1 over streams of one cell
+    // width) runs as its built-in straight-line kernel: from its first launch, inside a stream capture, without libhiprtc.
+    bool fixed = false;
+    ec_status fst = expr_fixed_launch(ea, n, out, out_mask, s, &fixed);
+    if (fst != EC_OK) return fst;
+    if (fixed) return check_launch("expr(ahead-of-time)");
     // The program compiled for itself (ec_expr_jit.hpp), once it is ready: values and the masks' AND as straight-line code in
     // one launch.  Until then — and whenever expr_jit is 0 — the interpreter below.
     bool compiled = false;
@@ -277,7 +286,19 @@ extern "C" ec_status ec_expr_source(const ec_dtype* dt, int32_t n_streams, int32
     ec_status st = program_of(ea, dt, n_streams, n_scalars, steps, n_steps, "ec_expr_source");
     if (st != EC_OK) return st;
     const char* variant = std::getenv("EC_EXPR_SOURCE_VARIANT");  // "reduce": the min_max variant (ec_expr_min_max) instead
-    const std::string src = expr_jit_source(ea, variant && !std::strcmp(variant, "reduce"));
+    std::string src;
+    {   // what the library makes of the program before it compiles anything: its canonical tree, and the built-in straight-line
+        // kernel that serves it if the tree is in the ahead-of-time catalogue (ec_expr_fixed.hpp) and the streams share one width
+        FixedMap fm;
+        int id = -1;
+        const std::string tree = expr_fixed_tree(ea, &fm, &id);
+        static const char* const kName[kFixCount] = {"NDVI", "add-mul", "EVI", "affine"};
+        bool one_width = id >= 0;
+        for (int k = 1; one_width && k < n_streams; ++k) one_width = ecl::size_of(dt[k]) == ecl::size_of(dt[0]);
+        src = "// tree: " + (tree.empty() ? std::string("(none within the catalogue's size)") : tree) + "\n// ahead-of-time kernel: " +
+              (id < 0 ? std::string("none (not in the catalogue)") : one_width ? std::string(kName[id]) : std::string(kName[id]) + " in the catalogue, but the streams differ in width: none") + "\n";
+    }
+    src += expr_jit_source(ea, variant && !std::strcmp(variant, "reduce"));
     if (len) *len = src.size() + 1;
     if (buf && cap > 0) {
         const size_t k = src.size() < cap - 1 ? src.size() : cap - 1;
@@ -286,7 +307,7 @@ extern "C" ec_status ec_expr_source(const ec_dtype* dt, int32_t n_streams, int32
     }
     if (arch_or_null) {
         std::string code, log;
-        return expr_jit_compile(src, arch_or_null, &code, &log);
+        return expr_jit_compile(src, arch_or_null, &code, &log);  // the two comment lines in front compile to nothing
     }
     return EC_OK;
 }

@@ -203,7 +203,7 @@ __device__ __forceinline__ void expr_mask_phase(const ExprArgs& ea, uint8_t* __r
                 policy_arms<1>(ea.cacheable >> (4 + k), [&](auto bits) { x = load_vec<!(decltype(bits)::value & 1u)>(mk); });
                 acc &= x;
             }
-            nt_store(acc, om + g);
+            mask_store(acc, om + g);
         }
         if (blockIdx.x == 0)
             for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) {

@@ -41,6 +41,9 @@ typedef U2 W4 __attribute__((aligned(1)));
 typedef U4 W8 __attribute__((aligned(1)));
 typedef D2 DO __attribute__((aligned(1)));
 typedef unsigned long long u64;
+// the result's 16-byte store: write-through and non-temporal, as the library's own value stores (ec_device.hpp stream_store_asm;
+// `s_nop 1`: a VALU write of the data registers needs two wait states behind a store of more than 64 bits)
+static __device__ __forceinline__ void st16(D2 v, DO* p) { asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v)); }
 #define FOR _Pragma("unroll") for (int i = 0; i < N; ++i)
 // cv_bin_op! on NaN (ec_device.hpp cell_op<OP, true>): the first NaN operand, quieted; the x86 default NaN when neither is one
 static __device__ __forceinline__ double fixnan(double t, double a, double b) {
@@ -274,7 +277,7 @@ std::string expr_jit_source(const ExprArgs& ea, bool reduce) {
     o += "            }\n        }\n    }\n"
          "    run<NC>(s0, s1, s2, s3, c0, c1, c2, c3, c4, c5, c6, c7, o);\n"
          "    _Pragma(\"unroll\") for (int j = 0; j < U; ++j) {\n        const unsigned long pr = base + j * 256ul;\n"
-         "        if (full || pr < npairs) __builtin_nontemporal_store(D2{o[2 * j], o[2 * j + 1]}, op + pr);\n    }\n"
+         "        if (full || pr < npairs) st16(D2{o[2 * j], o[2 * j + 1]}, op + pr);\n    }\n"
          "    if (blockIdx.x == 0 && threadIdx.x < 2) {  // the peeled head cell (lane 0) and the odd tail cell (lane 1)\n"
          "        const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;\n"
          "        const unsigned long i = threadIdx.x == 0 ? 0 : n - 1;\n"
@@ -446,14 +449,26 @@ struct Compiler {
             }
         });
     }
-    ~Compiler() {
+    // Stop and drain: the thread finishes the compile it is in (hiprtc offers no way to abandon one), programs still queued
+    // go back to "never compiled" and are queued again when they have run long enough.  Called by ec_shutdown (expr_jit_release),
+    // so that by the time the process runs static destructors — when the dlopen'ed libhiprtc may already be finalised — there
+    // is no compile in flight and nothing left to join; a later ec_init starts a fresh thread with the next request.
+    void stop() {
         {
             std::lock_guard<std::mutex> lk(g_mu);
             g_stop = true;
         }
         g_cv.notify_all();
         if (th.joinable()) th.join();
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& e : g_queue) {
+            e->work.store(0, std::memory_order_relaxed);
+            e->state.store(kNew, std::memory_order_release);
+        }
+        g_queue.clear();
+        g_stop = false;
     }
+    ~Compiler() { stop(); }
 };
 Compiler g_compiler;
 
@@ -507,8 +522,10 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* ou
             if (g_cache.size() >= kMaxPrograms) {
                 // a process that keeps inventing programs: forget those that never ran long enough to be compiled (they hold a
                 // work counter only); if every entry is a compiled program, the new one is interpreted
+                // — and that no caller holds at this moment (use_count 1: the cache's own reference; a caller takes its reference
+                // under g_mu): an entry erased under a caller that goes on to compile it would load a module nobody unloads
                 for (auto c = g_cache.begin(); c != g_cache.end();)
-                    c = c->second->state.load(std::memory_order_acquire) == kNew ? g_cache.erase(c) : std::next(c);
+                    c = (c->second.use_count() == 1 && c->second->state.load(std::memory_order_acquire) == kNew) ? g_cache.erase(c) : std::next(c);
                 if (g_cache.size() >= kMaxPrograms) return EC_OK;
             }
             it = g_cache.emplace(key, std::make_shared<Entry>()).first;
@@ -554,7 +571,10 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* ou
             st = check_hip(hipModuleLoadData(&mod, e->code.data()), "hipModuleLoadData(expression kernel)");
             if (st != EC_OK) return st;
             st = check_hip(hipModuleGetFunction(&fn, mod, "ec_expr_jit"), "hipModuleGetFunction(ec_expr_jit)");
-            if (st != EC_OK) return st;
+            if (st != EC_OK) {
+                (void)hipModuleUnload(mod);
+                return st;
+            }
             e->modules.emplace_back(dev, mod);
             e->fn.emplace(dev, fn);
         } else {
@@ -593,6 +613,7 @@ ec_status expr_jit_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* ou
 
 // ec_shutdown: unload the modules (the compiled code objects stay cached and are loaded again on demand)
 void expr_jit_release() {
+    g_compiler.stop();  // no compile in flight past this point
     std::vector<std::shared_ptr<Entry>> all;
     {
         std::lock_guard<std::mutex> lk(g_mu);

@@ -38,7 +38,7 @@ static ec_status launch_fused_any(FusedArgs& fa, int nops, size_t n, double* out
     size_t stream_bytes[8];
     for (int k = 0; k < 4; ++k) stream_bytes[k] = n * size_t(fused_class_bytes(cls[k]));  // 0: no stream of its own
     for (int j = 0; j < 4; ++j) stream_bytes[4 + j] = j < fa.nmask ? n : 0;
-    fa.cacheable = static_cast<uint8_t>(cache_plan(stream_bytes, 8));
+    fa.cacheable = static_cast<uint8_t>(cache_plan(stream_bytes, 8, n * sizeof(double)));
     const size_t per_tile = size_t(kBlock) * fused_u(narrowest);
     const unsigned grid = grid_for((((n - fa.head) >> 1) + per_tile - 1) / per_tile);
     FusedAnyKernel kern = nullptr;

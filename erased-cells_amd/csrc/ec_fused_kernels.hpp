@@ -96,7 +96,7 @@ __device__ __forceinline__ void fused_mask_phase(const FusedArgs& fa, uint8_t* _
                 policy_arms<1>(fa.cacheable >> (4 + k), [&](auto bits) { x = load_vec<!(decltype(bits)::value & 1u)>(mk); });  // launch-uniform
                 acc &= x;
             }
-            nt_store(acc, om + g);
+            mask_store(acc, om + g);
         }
         if (blockIdx.x == 0)
             for (size_t i = ngroups * 16 + threadIdx.x; i < n; i += kBlock) {

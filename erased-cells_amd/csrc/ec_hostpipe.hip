@@ -38,7 +38,7 @@ extern "C" ec_status ec_host_free(void* hptr) { return hptr ? check_hip(hipHostF
 
 namespace {
 struct PinTable {
-    struct Entry { size_t bytes; int refs; bool registered; };
+    struct Entry { size_t bytes; int refs; bool registered; bool refused; };  // refused: pin_all asked for a registration and the runtime said no
     std::mutex mu;
     std::condition_variable cv;
     std::multimap<uintptr_t, Entry> live;  // by (page-aligned) base: registrations made here, and ranges copied without one
@@ -66,53 +66,88 @@ std::vector<Interval> merged_pages(const std::vector<std::pair<const void*, size
 }
 
 // does any of `merged` collide with an entry of the table?  A registration collides when it overlaps without covering; a range in
-// use without a registration collides with a new REGISTRATION that overlaps it at all (two unregistered users never collide).
+// use without a registration collides with a new REGISTRATION that overlaps it at all (two unregistered users never collide) —
+// unless it is a range whose registration the runtime REFUSED and it covers the request: asking again would be refused again, so
+// the newcomer shares the entry and copies through the pageable path too.  That is what a shard's pipeline finds when
+// ec_sharded_host_expr could not page-lock the whole arrays (a locked-memory limit, a mapping the driver will not pin): before round 4 every shard waited here for
+// its own caller, forever.
 bool collides(const std::vector<Interval>& merged, bool want_registration) {
     for (const auto& m : merged)
         for (const auto& kv : g_pins.live) {
             const uintptr_t elo = kv.first, ehi = kv.first + kv.second.bytes;
             if (ehi <= m.first || m.second <= elo) continue;
+            const bool covers = elo <= m.first && m.second <= ehi;
             if (kv.second.registered) {
-                if (!(elo <= m.first && m.second <= ehi)) return true;
-            } else if (want_registration) {
+                if (!covers) return true;
+            } else if (want_registration && !(kv.second.refused && covers)) {
                 return true;
             }
         }
     return false;
 }
 
-// a registration in flight that covers [lo, hi)
-std::multimap<uintptr_t, PinTable::Entry>::iterator covering(const Interval& m) {
+// an entry in flight that covers [lo, hi) and may be shared: a registration, or (for pin_all) a range whose registration was refused
+std::multimap<uintptr_t, PinTable::Entry>::iterator covering(const Interval& m, bool or_refused = false) {
     for (auto it = g_pins.live.begin(); it != g_pins.live.end(); ++it)
-        if (it->second.registered && it->first <= m.first && m.second <= it->first + it->second.bytes) return it;
+        if ((it->second.registered || (or_refused && it->second.refused)) && it->first <= m.first && m.second <= it->first + it->second.bytes) return it;
     return g_pins.live.end();
+}
+
+// is [p, p + bytes) page-locked memory of the caller's own (ec_host_alloc / hipHostMalloc / its own hipHostRegister)?  Both ends
+// are asked: a pageable array may begin right behind a page-locked one.
+bool caller_pinned(const void* p, size_t bytes) {
+    for (const char* q : {static_cast<const char*>(p), static_cast<const char*>(p) + bytes - 1}) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, q) != hipSuccess || at.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();  // "not a HIP pointer" is an answer, not a failure
+            return false;
+        }
+    }
+    return true;
 }
 }  // namespace
 
 namespace ecd {
 
 void PinSet::pin_all(const std::vector<std::pair<const void*, size_t>>& ranges) {
-    const std::vector<Interval> merged = merged_pages(ranges);
+    // the caller's own page-locked arrays need nothing and are left out BEFORE the ranges are merged: judged per array, not per
+    // merged interval — an interval that begins in page-locked memory may run on into a pageable neighbour, whose copies are
+    // exactly what the table is there to guard
+    // — and judged UNDER the table's lock, against the table first: pages another call of the library has registered for the time being
+    // report as page-locked host memory too, and a range taken for the caller's own on that evidence would hold no reference when that
+    // call unregisters them (hipMemcpyAsync then fails with "invalid argument": the six-thread soak found this ordering within seconds)
+    const bool refuse_all = tuning().inject_pin_refusal.load() != 0;  // test hook: every registration "refused"
     std::unique_lock<std::mutex> lk(g_pins.mu);
-    while (collides(merged, true)) g_pins.cv.wait(lk);  // holding nothing while it waits: all of a call's ranges are taken at once
+    std::vector<Interval> merged;
+    for (;;) {
+        std::vector<std::pair<const void*, size_t>> mine;
+        for (const auto& r : ranges) {
+            if (!r.first || !r.second) continue;
+            const uintptr_t lo = reinterpret_cast<uintptr_t>(r.first), hi = lo + r.second;
+            bool ours = false;  // touches a registration the library made
+            for (const auto& kv : g_pins.live)
+                ours = ours || (kv.second.registered && kv.first < hi && lo < kv.first + kv.second.bytes);
+            if (ours || !caller_pinned(r.first, r.second)) mine.push_back(r);
+        }
+        merged = merged_pages(mine);
+        if (!collides(merged, true)) break;
+        g_pins.cv.wait(lk);  // holding nothing while it waits: all of a call's ranges are taken at once
+    }
     for (const auto& m : merged) {
-        auto it = covering(m);
-        if (it != g_pins.live.end()) {  // inside a registration in flight: share it
+        auto it = covering(m, true);
+        if (it != g_pins.live.end()) {  // inside a registration in flight, or inside a range that could not be registered: share it
             ++it->second.refs;
-            held_.push_back(Held{it->first, it->second.bytes, true});
+            held_.push_back(Held{it->first, it->second.bytes, it->second.registered, it->second.refused});
             continue;
         }
-        hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, reinterpret_cast<const void*>(m.first)) == hipSuccess && at.type == hipMemoryTypeHost) continue;  // the caller's own page-locked memory
-        (void)hipGetLastError();  // "not a HIP pointer" is an answer, not a failure
         // page-locked for every device: a shard group copies from it on all of them
-        if (hipHostRegister(reinterpret_cast<void*>(m.first), m.second - m.first, hipHostRegisterPortable) == hipSuccess) {
-            g_pins.live.emplace(m.first, PinTable::Entry{m.second - m.first, 1, true});
+        if (!refuse_all && hipHostRegister(reinterpret_cast<void*>(m.first), m.second - m.first, hipHostRegisterPortable) == hipSuccess) {
+            g_pins.live.emplace(m.first, PinTable::Entry{m.second - m.first, 1, true, false});
             held_.push_back(Held{m.first, m.second - m.first, true});
         } else {
-            (void)hipGetLastError();  // refused (a read-only mapping, ...): the runtime's pageable path copies such a range —
-            g_pins.live.emplace(m.first, PinTable::Entry{m.second - m.first, 1, false});  // — which makes it a range in use
-            held_.push_back(Held{m.first, m.second - m.first, false});
+            (void)hipGetLastError();  // refused (RLIMIT_MEMLOCK, a mapping the driver will not pin, ...): the runtime's pageable path copies such a range —
+            g_pins.live.emplace(m.first, PinTable::Entry{m.second - m.first, 1, false, true});  // — which makes it a range in use
+            held_.push_back(Held{m.first, m.second - m.first, false, true});
         }
     }
 }
@@ -127,7 +162,7 @@ void PinSet::use_all(const std::vector<std::pair<const void*, size_t>>& ranges) 
             ++it->second.refs;
             held_.push_back(Held{it->first, it->second.bytes, true});
         } else {
-            g_pins.live.emplace(m.first, PinTable::Entry{m.second - m.first, 1, false});
+            g_pins.live.emplace(m.first, PinTable::Entry{m.second - m.first, 1, false, false});
             held_.push_back(Held{m.first, m.second - m.first, false});
         }
     }
@@ -139,7 +174,7 @@ PinSet::~PinSet() {
     for (const Held& h : held_) {
         auto range = g_pins.live.equal_range(h.base);
         for (auto it = range.first; it != range.second; ++it) {
-            if (it->second.registered != h.registered || it->second.bytes != h.bytes) continue;
+            if (it->second.registered != h.registered || it->second.refused != h.refused || it->second.bytes != h.bytes) continue;
             if (--it->second.refs == 0) {
                 if (h.registered) (void)hipHostUnregister(reinterpret_cast<void*>(h.base));
                 g_pins.live.erase(it);

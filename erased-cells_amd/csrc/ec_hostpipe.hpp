@@ -24,7 +24,7 @@ namespace ecd {
 // entry points from five host threads.  Ranges in use without a registration make an overlapping registration wait; a range
 // inside a registration in flight shares it.
 class PinSet {
-    struct Held { uintptr_t base; size_t bytes; bool registered; };
+    struct Held { uintptr_t base; size_t bytes; bool registered; bool refused = false; };
     std::vector<Held> held_;  // table entries this object holds a reference on
 
 public:

@@ -171,7 +171,7 @@ struct MaskFromNodataFn {
         MV m;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) m[k] = x[k] != nd;
-        nt_store(m, reinterpret_cast<MV*>(mask) + g);
+        mask_store(m, reinterpret_cast<MV*>(mask) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { st_cell<uint8_t>(ld_cell(src + i) != nd, mask + i); }
 };
@@ -219,7 +219,7 @@ struct MaskBin {
         return In{load_vec<NT0>(reinterpret_cast<const u32x4*>(l) + g), load_vec<NT1>(reinterpret_cast<const u32x4*>(r) + g)};
     }
     __device__ __forceinline__ void store(size_t g, const In& in) const {
-        nt_store(KIND == 0 ? (in.a & in.b) : (in.a | in.b), reinterpret_cast<u32x4*>(out) + g);
+        mask_store(KIND == 0 ? (in.a & in.b) : (in.a | in.b), reinterpret_cast<u32x4*>(out) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const {
         const uint8_t a = ld_cell(l + i), b = ld_cell(r + i);
@@ -236,7 +236,7 @@ struct MaskNot {
     template <bool NT0, bool NT1>
     __device__ __forceinline__ In load(size_t g) const { return load_vec<NT0>(reinterpret_cast<const u32x4*>(m) + g); }
     __device__ __forceinline__ void store(size_t g, const In& x) const {
-        nt_store(x ^ 0x01010101u, reinterpret_cast<u32x4*>(out) + g);
+        mask_store(x ^ 0x01010101u, reinterpret_cast<u32x4*>(out) + g);
     }
     __device__ __forceinline__ void cell(size_t i) const { st_cell<uint8_t>(ld_cell(m + i) ^ 1, out + i); }
 };

@@ -461,7 +461,23 @@ extern "C" ec_status ec_stream_sync(ec_stream s) { return check_hip(hipStreamSyn
 extern "C" ec_status ec_stat_get(const char* key, int64_t* value) {
     if (!key || !value) return set_error(EC_ERR_ARG, "ec_stat_get: null argument");
     if (!std::strcmp(key, "pool_allocs")) *value = g_pool_allocs.load(std::memory_order_relaxed);
-    else if (!std::strcmp(key, "devices")) {
+    else if (!std::strncmp(key, "tune.", 5)) {  // the current value of a knob of ec_tune_set, so that a caller can put it back
+        const char* k = key + 5;
+        if (!std::strcmp(k, "binop_variant")) *value = g_tuning.binop_variant;
+        else if (!std::strcmp(k, "reduce_bpc")) *value = g_tuning.reduce_bpc;
+        else if (!std::strcmp(k, "reduce_shape")) *value = g_tuning.reduce_shape;
+        else if (!std::strcmp(k, "map_u")) *value = g_tuning.map_u;
+        else if (!std::strcmp(k, "peel")) *value = g_tuning.peel;
+        else if (!std::strcmp(k, "unaligned_vector")) *value = g_tuning.unaligned_vector;
+        else if (!std::strcmp(k, "fused_mixed")) *value = g_tuning.fused_mixed;
+        else if (!std::strcmp(k, "mall_mb")) *value = g_tuning.mall_mb;
+        else if (!std::strcmp(k, "expr_jit")) *value = g_tuning.expr_jit;
+        else if (!std::strcmp(k, "expr_fixed")) *value = g_tuning.expr_fixed;
+        else if (!std::strcmp(k, "write_lds_kb")) *value = g_tuning.write_lds_kb;
+        else if (!std::strcmp(k, "cache_force")) *value = g_tuning.cache_force;
+        else if (!std::strcmp(k, "pool_keep_mb")) *value = g_tuning.pool_keep_mb;
+        else return set_error(EC_ERR_ARG, "ec_stat_get: unknown knob '%s'", k);
+    } else if (!std::strcmp(key, "devices")) {
         std::lock_guard<std::mutex> lk(g_mu);
         *value = static_cast<int64_t>(g_devs.size());
     } else if (!std::strcmp(key, "scratch_streams")) {
@@ -489,6 +505,10 @@ extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     else if (!std::strcmp(key, "fused_mixed")) g_tuning.fused_mixed = static_cast<int>(value);
     else if (!std::strcmp(key, "mall_mb")) g_tuning.mall_mb = value < 0 ? 0 : value;
     else if (!std::strcmp(key, "inject_shard_failure")) g_tuning.inject_shard_failure = static_cast<int>(value);
+    else if (!std::strcmp(key, "inject_pin_refusal")) g_tuning.inject_pin_refusal = value != 0;
+    else if (!std::strcmp(key, "expr_fixed")) g_tuning.expr_fixed = value != 0;
+    else if (!std::strcmp(key, "write_lds_kb")) g_tuning.write_lds_kb = value < 0 ? 0 : value > 64 ? 64 : static_cast<int>(value);
+    else if (!std::strcmp(key, "cache_force")) g_tuning.cache_force = value < 0 ? -1 : static_cast<int>(value);
     else if (!std::strcmp(key, "expr_jit")) g_tuning.expr_jit = value < 0 ? 0 : value > 2 ? 2 : static_cast<int>(value);
     else if (!std::strcmp(key, "pool_keep_mb")) {
         g_tuning.pool_keep_mb = value < 0 ? 0 : value;

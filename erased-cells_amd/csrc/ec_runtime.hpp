@@ -46,8 +46,17 @@ struct Tuning {
                                            // the default cache policy, all others non-temporal; 0 = every stream non-temporal
     std::atomic<int> inject_shard_failure{0};  // test hook: shard index + 1 whose NEXT fire-and-forget job of a shard group reports
                                                // EC_ERR_HIP instead of launching (exercises the deferred-error path); 0 = off
+    std::atomic<int> inject_pin_refusal{0};    // test hook: 1 = PinSet::pin_all treats every hipHostRegister as refused, so the
+                                               // pageable fallback of the host-to-host pipelines is exercised
     std::atomic<int> expr_jit{1};  // expression programs compiled at run time (ec_expr_jit.hpp): 0 never, 1 in the background once a
                                    // program has interpreted 2^31 cell-steps, 2 on the calling thread at first sight
+    std::atomic<int> expr_fixed{1};  // 1 (default): a program of the ahead-of-time catalogue (ec_expr_fixed.hpp) runs as its built-in straight-line
+                                     // kernel; 0: never (the interpreter / the compiled form serve it — the comparison path of the tests)
+    std::atomic<int> write_lds_kb{64};  // LDS reserved per workgroup of a PURE-WRITE launch (fill, the generators): caps the workgroups resident
+                                        // per CU (64 KiB: two of 160 KiB).  A write-only stream runs faster from few resident waves — 0.85 of the HBM
+                                        // peak at full occupancy, 0.88-0.90 at 2-3 workgroups per CU, 0.93 with write-through stores on top
+                                        // (profiles/r04/tune_store_v2.log); any launch that also loads needs its occupancy and gets none.  0 = no cap
+    std::atomic<int> cache_force{-1};  // A/B hook: >= 0 replaces cache_plan()'s answer by these bits for every launch (profiles/r04/cache_plan_ab.md)
     std::atomic<int64_t> pool_keep_mb{32768};  // release threshold of the library's stream-ordered pool (per device)
 };
 
@@ -96,10 +105,20 @@ inline unsigned peel_head(const void* l, size_t lsize, const void* r, size_t rsi
 // tune_nt_width_rotating.log): the u8 ÷ u16 divide with its 256 MiB u8 operand cacheable runs at 0.856 of the HBM peak
 // when that operand was touched by the previous launch and 0.792 when it was not; with every load nt, 0.80 either way.
 // Big streams want nt: a 2 GiB read-only stream reaches 0.865 nt against 0.76 cacheable.
-inline unsigned cache_plan(const size_t* bytes, int n) {
+//
+// `value_out_bytes` (round 4): the f64 result the launch streams out, for the kernels that write one (binop, fused, expr).  With it
+// a second rule applies: if a stream is LEFT OUT that is no bigger than one that was admitted — two equal operands of which only one
+// fits — nothing is admitted.  Measured (profiles/r04/cache_plan_ab.md): u8 ∘ u8 → f64 at 16384² with one of its two 256 MiB operands
+// cacheable runs 1.5 % (add) to 7 % (divide) SLOWER in the one-set loop than with every load nt — at any relative placement of the
+// two buffers (tools/cache_conflict_probe.py), with either one admitted — while u8 ∘ u16 with its u8 operand cacheable runs 5-8 %
+// faster, and the 1 B/cell kernels (mask_and with one of two masks cacheable: 0.93 against 0.80) keep their gain: they pass 0 here.
+// An operand that is never read again costs at most 0.6 % under either rule (the rotating-set column of the same table).
+inline unsigned cache_plan(const size_t* bytes, int n, size_t value_out_bytes = 0) {
+    const int forced = tuning().cache_force.load();
+    if (forced >= 0) return static_cast<unsigned>(forced) & ((1u << (n < 8 ? n : 8)) - 1u);
     const size_t budget = static_cast<size_t>(tuning().mall_mb.load()) << 20;
     unsigned plan = 0;
-    size_t used = 0;
+    size_t used = 0, largest_taken = 0;
     bool taken[8] = {false, false, false, false, false, false, false, false};
     for (int round = 0; round < n && n <= 8; ++round) {
         int best = -1;
@@ -108,8 +127,12 @@ inline unsigned cache_plan(const size_t* bytes, int n) {
         if (best < 0 || used + bytes[best] > budget) break;
         taken[best] = true;
         used += bytes[best];
+        if (bytes[best] > largest_taken) largest_taken = bytes[best];
         plan |= 1u << best;
     }
+    if (value_out_bytes > 0 && plan != 0)
+        for (int k = 0; k < n && n <= 8; ++k)
+            if (!taken[k] && bytes[k] > 0 && bytes[k] <= largest_taken) return 0;  // an equal (or smaller) peer does not fit: admit none
     return plan;
 }
 

@@ -631,11 +631,21 @@ extern "C" ec_status ec_sharded_host_expr(ec_shard_group* g, const ec_dtype* dt,
     }
     for (int k = 0; k < n_streams; ++k)
         if (!p_host[k]) return set_error(EC_ERR_ARG, "ec_sharded_host_expr: stream %d is null", k);
+    // everything a shard's pipeline would refuse is refused here, on the calling thread, before a page is locked
+    if (nodata_or_null)
+        for (int k = 0; k < n_streams; ++k)
+            if (nodata_or_null[k] && nodata_or_null[k]->dtype != dt[k])
+                return set_error(EC_ERR_ARG, "ec_sharded_host_expr: nodata[%d] has cell type %d, its stream %d", k, int(nodata_or_null[k]->dtype), int(dt[k]));
+    if (n_cols != 0 && n_rows > (UINT64_MAX / 8) / n_cols)  // n cells of at most 8 bytes: the byte counts below stay inside 64 bits
+        return set_error(EC_ERR_ARG, "ec_sharded_host_expr: %llu x %llu cells overflow the address space", (unsigned long long)n_rows, (unsigned long long)n_cols);
+    if ((st = ensure_ready()) != EC_OK) return st;
     // the WHOLE arrays are page-locked once, here; the shards' pipelines find their row-blocks inside these registrations
-    // (row-blocks end in the middle of pages: registering them one by one would collide on the shared pages)
+    // (row-blocks end in the middle of pages: registering them one by one would collide on the shared pages).  Arrays the runtime
+    // refuses to register stay in the table as ranges in use; the shards share those entries and copy
+    // through the pageable path (PinSet, ec_hostpipe.hip)
     const uint64_t n = n_rows * n_cols;
     PinSet whole;
-    if (ensure_ready() == EC_OK) {
+    {
         std::vector<std::pair<const void*, size_t>> ranges;
         for (int k = 0; k < n_streams; ++k) ranges.emplace_back(p_host[k], n * ecl::size_of(dt[k]));
         ranges.emplace_back(out_host, n * sizeof(double));

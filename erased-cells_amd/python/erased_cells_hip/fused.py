@@ -105,17 +105,21 @@ def program(streams, scalars, steps):
 class jit:
     """`with fused.jit(2): ...` — how expression programs are run inside the block (`ec_tune_set("expr_jit", mode)`): 0 the
     interpreter kernel only, 1 compiled in the background once a program has run long enough (the default), 2 compiled on the
-    calling thread at first sight.  The previous default (1) is restored on exit."""
+    calling thread at first sight.  The mode that was in force before the block is restored on exit (blocks nest)."""
 
     def __init__(self, mode: int):
         self.mode = mode
+        self.previous = 1
 
     def __enter__(self):
+        prev = C.c_int64(1)
+        check(lib().ec_stat_get(b"tune.expr_jit", C.byref(prev)))
+        self.previous = prev.value
         check(lib().ec_tune_set(b"expr_jit", self.mode))
         return self
 
     def __exit__(self, *exc):
-        check(lib().ec_tune_set(b"expr_jit", 1))
+        check(lib().ec_tune_set(b"expr_jit", self.previous))
         return False
 
 

@@ -1,7 +1,9 @@
 /* An operator tree of any depth in ONE pass from plain C: EVI = 2.5 (nir - red) / (nir + 6 red - 7.5 blue + 1) over three
  * u16 bands, as an expression program (ec_expr) — what the reference evaluates as eight passes with seven f64 temporaries
  * (impl $trt for &CellBuffer, src/buffer.rs:324-352).  The result is compared, bit for bit, with the same eight operators run
- * one by one through ec_binop / ec_binop_scalar, twice: interpreted (expr_jit = 0) and compiled for itself (expr_jit = 2).
+ * one by one through ec_binop / ec_binop_scalar, three times: as the library runs it by default (EVI over bands of one width is in
+ * its ahead-of-time catalogue: a built-in straight-line kernel), and with that turned off (expr_fixed = 0) interpreted
+ * (expr_jit = 0) and compiled for itself through hiprtc (expr_jit = 2).
  *
  *   gcc -std=c99 -Iinclude examples/evi.c -Lerased-cells_amd -lerased_cells_hip -Wl,-rpath,$PWD/erased-cells_amd -o evi
  */
@@ -43,7 +45,7 @@ int main(void) {
         {EC_ADD, EC_EXPR_REG(1), EC_EXPR_SCALAR(3), 1},    {EC_DIV, EC_EXPR_REG(0), EC_EXPR_REG(1), 0}};
     const ec_dtype dt[3] = {EC_U16, EC_U16, EC_U16};
     const void *p[3];
-    int64_t interpreted = 0, compiled = 0;
+    int64_t interpreted = 0, compiled = 0, builtin = 0;
     size_t i;
     int mode;
 
@@ -74,8 +76,9 @@ int main(void) {
     p[0] = dn;
     p[1] = dr;
     p[2] = db;
-    for (mode = 0; mode <= 2; mode += 2) { /* the interpreter kernel, then the program compiled for itself (hiprtc) */
-        CHECK(ec_tune_set("expr_jit", mode));
+    for (mode = -1; mode <= 2; mode += mode < 0 ? 1 : 2) { /* the built-in kernel; then, without it: the interpreter kernel, the program compiled for itself (hiprtc) */
+        CHECK(ec_tune_set("expr_fixed", mode < 0));
+        CHECK(ec_tune_set("expr_jit", mode < 0 ? 0 : mode));
         memset(got, 0, sizeof got);
         CHECK(ec_upload(out, got, sizeof got, NULL));
         CHECK(ec_expr(dt, p, 3, k, 4, prog, 8, N, (double *)out, NULL));
@@ -87,8 +90,9 @@ int main(void) {
     }
     CHECK(ec_stat_get("expr_interp_launches", &interpreted));
     CHECK(ec_stat_get("expr_jit_launches", &compiled));
-    printf("EVI[0] = %.17g, %d cells, one pass == eight passes; interpreted launches %d, compiled launches %d\n", got[0], (int)N,
-           (int)interpreted, (int)compiled);
+    CHECK(ec_stat_get("expr_fixed_launches", &builtin));
+    printf("EVI[0] = %.17g, %d cells, one pass == eight passes; built-in launches %d, interpreted launches %d, compiled launches %d\n", got[0],
+           (int)N, (int)builtin, (int)interpreted, (int)compiled);
     CHECK(ec_free(dn));
     CHECK(ec_free(dr));
     CHECK(ec_free(db));
@@ -97,6 +101,7 @@ int main(void) {
     CHECK(ec_shutdown());
     /* the library again after a shutdown: the compiled program is still cached, its module is loaded anew */
     CHECK(ec_init(0));
+    CHECK(ec_tune_set("expr_fixed", 0));
     CHECK(ec_tune_set("expr_jit", 2));
     CHECK(ec_alloc(&dn, sizeof nir));
     CHECK(ec_alloc(&dr, sizeof red));
@@ -121,5 +126,5 @@ int main(void) {
     CHECK(ec_free(db));
     CHECK(ec_free(out));
     CHECK(ec_shutdown());
-    return !(interpreted == 1);
+    return !(interpreted == 1 && builtin == 1);
 }

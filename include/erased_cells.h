@@ -238,8 +238,14 @@ ec_status ec_expr_min_max_keys(const ec_dtype *dt, const void *const *p, const u
                                int32_t n_streams, const ec_value *scalars, int32_t n_scalars, const ec_expr_step *steps,
                                int32_t n_steps, size_t n, int64_t *keys2_dev, ec_stream stream);
 
-/* How ec_expr runs a program.  The kernel that serves every program is an interpreter (a step is decoded once per wave):
- * bound by instruction issue, ≈ 0.04 ms per step over 16384^2 cells beyond the first.  A program is launch-uniform, so
+/* How ec_expr runs a program.  Three forms, the same cells from each.  (1) Ahead of time: the programs whose TREE is one
+ * of NDVI `(a - b) / (a + b)`, `(a + b) * c`, EVI `((a - b) * k0) / (((a + b * k1) - c * k2) + k3)` and `a * k0 + k1`, over
+ * distinct streams of one cell width, are built into the library as straight-line kernels (csrc/ec_expr_fixed.hpp) and run
+ * that way from their first launch, inside stream captures and without hiprtc; register names, the schedule of independent
+ * sub-trees, the numbering of streams and scalars and the side a lone scalar of + or * stands on do not matter
+ * (ec_tune_set("expr_fixed", 0) turns this off; ec_stat_get "expr_fixed_launches").  (2) The kernel that serves every
+ * other program is an interpreter (a step is decoded once per wave):
+ * bound by instruction issue, ≈ 0.04 ms per step over 16384^2 cells beyond the first.  (3) A program is launch-uniform, so
  * the library can also compile it for itself — straight-line code with typed loads, through hiprtc (resolved lazily;
  * without it the interpreter keeps serving) — and cache the module per (program, cell types, load policy).  Same cells
  * either way.  ec_tune_set("expr_jit", v): 0 = never compile; 1 (default) = compile on a background thread once a
@@ -468,7 +474,8 @@ ec_status ec_synth_mask(uint8_t *dst, size_t n, uint64_t seed, uint64_t base, ui
 ec_status ec_tune_set(const char *key, int64_t value);
 /* Counters for tests: "pool_allocs" (ec_alloc_async calls so far, including those the library makes itself — a call
  * that leaves it unchanged allocated nothing), "devices" (initialised devices), "scratch_streams" (streams the
- * library currently holds reduction scratch for). */
+ * library currently holds reduction scratch for); "tune.<knob>": the current value of a knob of ec_tune_set (so that a
+ * scope that turns one can put the previous value back). */
 ec_status ec_stat_get(const char *key, int64_t *value);
 
 #ifdef __cplusplus

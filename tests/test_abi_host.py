@@ -196,11 +196,11 @@ def test_header_is_plain_c99_and_links_from_c(tmp_path):
 @pytest.mark.gpu
 def test_evi_expression_program_from_plain_c(tmp_path):
     """examples/evi.c: an eight-operator tree as one ec_expr call from C equals the eager chain of the same operators bit for
-    bit, interpreted and compiled for itself."""
+    bit — as the built-in kernel of the ahead-of-time catalogue, interpreted, and compiled for itself."""
     import subprocess
     r = subprocess.run([_build_c_example(tmp_path, "evi")], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "one pass == eight passes; interpreted launches 1, compiled launches 1" in r.stdout
+    assert "one pass == eight passes; built-in launches 1, interpreted launches 1, compiled launches 1" in r.stdout
 
 
 @pytest.mark.gpu

@@ -43,6 +43,17 @@ def test_bench_emits_one_json_line_with_roofline_and_cpu_baseline():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert abs(rf["achieved"] - 11 * rf["cells_per_launch"] / (rf["launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
     assert 0.05 < rf["frac"] < 1.0
+    # the headline is an all-HBM figure: the timed steps rotate over >= 4 operand sets with >= 1 GiB between two uses of a byte;
+    # the one-set loop of rounds 1-3 is a side figure, for every rank
+    cfg = d["config"]
+    assert rf["all_hbm"] is True and cfg["operand_sets"] >= 4 and "rotation" in cfg
+    assert (cfg["operand_sets"] - 1) * cfg["operand_set_bytes_per_rank"] >= 1 << 30
+    assert cfg["operand_set_bytes_per_rank"] == 11 * rf["cells_per_launch"]
+    assert cfg["untimed_steps_before_timing"] == cfg["clock_ramp_steps"] + d["warmup"]
+    loop = rf["cache_resident_loop"]
+    assert loop["operand_sets"] == 1 and 0.05 < loop["frac"] and "NOT an HBM figure" in loop["what"]
+    assert abs(loop["frac"] - 11 * rf["cells_per_launch"] / (loop["launch_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    assert rf["per_gpu"][0]["cache_resident_loop"]["launch_ms"] == loop["launch_ms"] and "fresh_inputs" not in rf
     rs = rf["reference_streams"]  # untimed plain streams of the same buffers (SURVEY §8d "empirical ceiling")
     assert all(0 < rs[k] < 8000.0 for k in ("same_mix_add_u8_u16_GBps", "write_only_fill_f64_GBps", "read_only_min_max_f64_GBps"))
     cb = d["cpu_baseline"]
@@ -84,6 +95,10 @@ def test_bench_self_launched_two_ranks_rehearsal_on_one_gpu():
     pg = d["roofline"]["per_gpu"]
     assert [g["rank"] for g in pg] == [0, 1] and all(g["cells"] == 4096 * 2048 and 0 < g["frac"] < 1 for g in pg)
     assert abs(d["roofline"]["launch_ms"] - max(g["launch_ms"] for g in pg)) < 1e-12
+    # every rank rotates its own shard's operand sets and reports both figures
+    assert d["roofline"]["all_hbm"] is True and d["config"]["operand_sets"] >= 4
+    assert all(g["cache_resident_loop"]["frac"] > 0 for g in pg)  # may exceed 1: a 92 MB set lives in the Infinity Cache — not an HBM figure
+    assert abs(d["roofline"]["cache_resident_loop"]["launch_ms"] - max(g["cache_resident_loop"]["launch_ms"] for g in pg)) < 1e-12
     assert "cpu_baseline" not in d  # rank 0 at N=1 only
 
 

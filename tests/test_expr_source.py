@@ -117,3 +117,39 @@ def test_reduce_variant_compiles_and_stores_nothing_but_its_keys(monkeypatch):
     src = ec.fused.program_source([ec.UInt16, ec.UInt16], 0, ndvi, arch="gfx950")
     body = src[src.index("static __device__ __forceinline__ void run("):src.index("static __device__ __forceinline__ long long okey")]
     assert "= divs(r0[i], r1[i]);" in body and "NANFIX(" not in body
+
+
+def _tree(cts, nscal, steps):
+    src = ec.fused.program_source(cts, nscal, steps)
+    lines = src.splitlines()
+    assert lines[0].startswith("// tree: ") and lines[1].startswith("// ahead-of-time kernel: ")
+    return lines[0][len("// tree: "):], lines[1][len("// ahead-of-time kernel: "):]
+
+
+def test_a_program_is_recognised_by_its_tree_not_by_its_step_list():
+    """The ahead-of-time catalogue (csrc/ec_expr_fixed.hpp) is looked up by the expression a step list computes: register
+    names, the schedule of independent sub-trees, the numbering of streams and scalars and the side a lone scalar of + or *
+    stands on do not matter; operand order of everything else does."""
+    U16, I16, F32 = ec.UInt16, ec.Int16, ec.Float32
+    evi_tree = "(/ (* (- S0 S1) K0) (+ (- (+ S0 (* S1 K1)) (* S2 K2)) K3))"
+    assert _tree([U16, I16, U16], 4, EVI) == (evi_tree, "EVI")
+    # the denominator first, other registers, scalars on the left, streams and scalars numbered differently:
+    # 2.5 * (nir - red) / (nir + 6 * red - 7.5 * blue + 1) with nir = stream 2, red = stream 0, blue = stream 1
+    other = [(ec.MUL, K(3), S(0), 3), (ec.ADD, S(2), R(3), 3), (ec.MUL, K(0), S(1), 0), (ec.SUB, R(3), R(0), 2), (ec.ADD, R(2), K(1), 2),
+             (ec.SUB, S(2), S(0), 1), (ec.MUL, K(2), R(1), 1), (ec.DIV, R(1), R(2), 0)]
+    assert _tree([U16, U16, U16], 4, other) == (evi_tree, "EVI")
+    # NDVI with its sum first; a dead step in between drops out
+    ndvi = [(ec.ADD, S(0), S(1), 2), (ec.MUL, S(0), S(0), 3), (ec.SUB, S(0), S(1), 1), (ec.DIV, R(1), R(2), 0)]
+    assert _tree([F32, F32], 0, ndvi) == ("(/ (- S0 S1) (+ S0 S1))", "NDVI")
+    # (red - nir) / (nir + red) is another tree: operand order of stream operands is kept
+    assert _tree([F32, F32], 0, [(ec.SUB, S(1), S(0), 0), (ec.ADD, S(0), S(1), 1), (ec.DIV, R(0), R(1), 0)])[0] == "(/ (- S0 S1) (+ S1 S0))"
+    assert _tree([ec.UInt8, ec.Int8, ec.UInt8], 0, [(ec.ADD, S(0), S(1), 0), (ec.MUL, R(0), S(2), 0)]) == ("(* (+ S0 S1) S2)", "add-mul")
+    assert _tree([ec.Float64], 2, [(ec.MUL, K(1), S(0), 2), (ec.ADD, K(0), R(2), 2)]) == ("(+ (* S0 K0) K1)", "affine")
+    # in the catalogue, but streams of different widths: the interpreter / the compiled form serve it
+    t, k = _tree([U16, F32], 0, [(ec.SUB, S(0), S(1), 0), (ec.ADD, S(0), S(1), 1), (ec.DIV, R(0), R(1), 0)])
+    assert t == "(/ (- S0 S1) (+ S0 S1))" and k.startswith("NDVI in the catalogue, but")
+    # not in the catalogue; a subtraction's scalar is never moved; a register read twice is written out twice
+    assert _tree([U16], 1, [(ec.SUB, K(0), S(0), 0)]) == ("(- K0 S0)", "none (not in the catalogue)")
+    assert _tree([U16], 0, [(ec.ADD, S(0), S(0), 0), (ec.MUL, R(0), R(0), 1)])[0] == "(* (+ S0 S0) (+ S0 S0))"
+    # a long chain has no bounded tree
+    assert _tree([U16], 1, [(ec.MUL, S(0), K(0), 0)] + [(ec.ADD, R(0), R(0), 0)] * 15)[0].startswith("(none")

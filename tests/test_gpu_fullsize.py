@@ -189,9 +189,10 @@ def test_indexing_beyond_2_32_cells(ec):
 
 
 def test_evi_expression_program_16384sq_three_ways(ec):
-    """An eight-operator tree at raster scale (three 16384² u16 bands, bench.py's `--workload evi` inputs): the interpreter
-    kernel, the program compiled for itself and the eager chain of eight operators agree on every cell (compared on the
-    device), and the ends and the middle of the raster agree with the oracle's step-by-step evaluation."""
+    """An eight-operator tree at raster scale (three 16384² u16 bands, bench.py's `--workload evi` inputs): the built-in kernel
+    of the ahead-of-time catalogue (what runs by default), the interpreter kernel, the program compiled for itself and the eager
+    chain of eight operators agree on every cell (compared on the device), and the ends and the middle of the raster agree
+    with the oracle's step-by-step evaluation."""
     L, E, P = ec.lib(), ec._ffi, ec.fused
     bands, seeds = [], (0x5EED0031, 0x5EED0032, 0x5EED0033)
     ranges = [(2000 + 3000 * (2 - i), 20000 + 10000 * (2 - i)) for i in range(3)]
@@ -204,14 +205,28 @@ def test_evi_expression_program_16384sq_three_ways(ec):
     prog = [(ec.SUB, S(0), S(1), 0), (ec.MUL, R(0), K(0), 0), (ec.MUL, S(1), K(1), 1), (ec.ADD, S(0), R(1), 1),
             (ec.MUL, S(2), K(2), 2), (ec.SUB, R(1), R(2), 1), (ec.ADD, R(1), K(3), 1), (ec.DIV, R(0), R(1), 0)]
     ks = [2.5, 6.0, 7.5, 1.0]
+    def stat(key):
+        v = C.c_int64(0)
+        _chk(ec, L.ec_stat_get(key, C.byref(v)))
+        return v.value
+
     try:
         L.ec_tune_set(b"expr_jit", 0)
+        f0 = stat(b"expr_fixed_launches")
+        builtin = P.program(bands, ks, prog)
+        assert stat(b"expr_fixed_launches") == f0 + 1
+        L.ec_tune_set(b"expr_fixed", 0)
+        i0 = stat(b"expr_interp_launches")
         interpreted = P.program(bands, ks, prog)
+        assert stat(b"expr_interp_launches") == i0 + 1
         L.ec_tune_set(b"expr_jit", 2)
         compiled = P.program(bands, ks, prog)
     finally:
         L.ec_tune_set(b"expr_jit", 1)
+        L.ec_tune_set(b"expr_fixed", 1)
     assert interpreted == compiled                      # ec_buffer_cmp: first differing cell on the device, none
+    assert builtin == compiled
+    del builtin
     eager = ((nir - red) * 2.5) / (((nir + red * 6.0) - blue * 7.5) + 1.0)
     assert eager == compiled
     del interpreted, eager

@@ -1147,3 +1147,155 @@ def test_fused_ndvi_small_integer_divide_is_exact_for_every_numerator_and_denomi
             orc.check(fused.data_ptr(), n, f"fused NDVI {tname}, denominators from {b0}")
     finally:
         orc.close()
+
+
+# ---- the ahead-of-time catalogue of expression programs (csrc/ec_expr_fixed.hpp): 4 formulas x 4 cell widths = 16 kernels
+_S, _R, _K = (lambda k: k), (lambda k: 4 + k), (lambda k: 8 + k)
+_FIXED = {
+    "ndvi": (2, [], [[(eco.SUB, _S(0), _S(1), 0), (eco.ADD, _S(0), _S(1), 1), (eco.DIV, _R(0), _R(1), 0)],
+                     [(eco.ADD, _S(0), _S(1), 3), (eco.SUB, _S(0), _S(1), 2), (eco.DIV, _R(2), _R(3), 1)]]),
+    "add-mul": (3, [], [[(eco.ADD, _S(0), _S(1), 0), (eco.MUL, _R(0), _S(2), 0)],
+                        [(eco.ADD, _S(0), _S(1), 2), (eco.MUL, _R(2), _S(2), 3)]]),
+    "evi": (3, [2.5, 6.0, 7.5, 1.0],
+            [[(eco.SUB, _S(0), _S(1), 0), (eco.MUL, _R(0), _K(0), 0), (eco.MUL, _S(1), _K(1), 1), (eco.ADD, _S(0), _R(1), 1),
+              (eco.MUL, _S(2), _K(2), 2), (eco.SUB, _R(1), _R(2), 1), (eco.ADD, _R(1), _K(3), 1), (eco.DIV, _R(0), _R(1), 0)],
+             # denominator first, scalars on the left of their products
+             [(eco.MUL, _K(1), _S(1), 3), (eco.ADD, _S(0), _R(3), 3), (eco.MUL, _K(2), _S(2), 0), (eco.SUB, _R(3), _R(0), 2),
+              (eco.ADD, _R(2), _K(3), 2), (eco.SUB, _S(0), _S(1), 1), (eco.MUL, _K(0), _R(1), 1), (eco.DIV, _R(1), _R(2), 0)]]),
+    "affine": (1, [0.0001, -273.15], [[(eco.MUL, _S(0), _K(0), 0), (eco.ADD, _R(0), _K(1), 0)],
+                                      [(eco.MUL, _K(0), _S(0), 2), (eco.ADD, _K(1), _R(2), 1)]]),
+}
+
+
+@pytest.mark.gpu
+def test_expr_ahead_of_time_kernels_every_formula_every_width(ec, pool):
+    """All 16 `k_expr_fixed<formula, width>` kernels, every cell kind inside each width: a catalogue formula — in two spellings
+    each (other registers, other schedule, scalars on the other side) — runs as ONE launch of its built-in kernel
+    (`expr_fixed_launches`), with expr_jit = 0 and no interpreter launch, and gives the oracle's step-by-step cells and, bit for
+    bit, the interpreter's (`expr_fixed` = 0) — over whole tiles, a ragged tail, odd windows (peeled head, odd last cell), one
+    and two cells, plain and masked."""
+    host, dev, m, dm = pool
+    P, L = ec.fused, ec.lib()
+    L.ec_tune_set(b"expr_jit", 0)
+    try:
+        tick = 0
+        for name, (ns, scalars, spellings) in _FIXED.items():
+            for width, cts_of in _BY_WIDTH.items():
+                for rot in range(len(cts_of)):
+                    cts = [cts_of[(rot + k) % len(cts_of)] for k in range(ns)]  # kinds differ between the streams of one launch
+                    for n, off in ((N, 0), (2049, 3), (1, 0), (2, 1)):
+                        tick += 1
+                        bufs = [dev[ct].shard(off + k, n) for k, ct in enumerate(cts)]
+                        hs = [host[ct][off + k:off + k + n] for k, ct in enumerate(cts)]
+                        steps = spellings[tick % 2]
+                        f0, i0 = _stat(ec, b"expr_fixed_launches"), _stat(ec, b"expr_interp_launches")
+                        masked = tick % 3 == 0
+                        if masked:
+                            got_m = P.program([ec.MaskedCellBuffer(b, dm[k % 2].shard(off + k, n)) for k, b in enumerate(bufs)], scalars, steps)
+                            got = got_m.buffer()
+                            want_mask = np.ones(n, np.uint8)
+                            for k in range(ns):
+                                want_mask &= m[k % 2][off + k:off + k + n]
+                            assert np.array_equal(got_m.mask().to_numpy(), want_mask)
+                        else:
+                            got = P.program(bufs, scalars, steps)
+                        assert _stat(ec, b"expr_fixed_launches") == f0 + 1 and _stat(ec, b"expr_interp_launches") == i0, (name, cts, n)
+                        eo, loose = _oracle_program(hs, scalars, spellings[0])
+                        try:
+                            assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+                        except AssertionError as e:
+                            raise AssertionError(f"{name} types {cts} n {n} off {off}: {e}") from None
+                        L.ec_tune_set(b"expr_fixed", 0)
+                        try:
+                            interp = P.program(bufs, scalars, steps)
+                            assert _stat(ec, b"expr_interp_launches") == i0 + 1
+                        finally:
+                            L.ec_tune_set(b"expr_fixed", 1)
+                        assert np.array_equal(bits_of(got.to_numpy()), bits_of(interp.to_numpy())), (name, cts, n, off)
+    finally:
+        L.ec_tune_set(b"expr_jit", 1)
+
+
+@pytest.mark.gpu
+def test_expr_ahead_of_time_near_misses_stay_with_the_interpreter(ec, pool):
+    """What is NOT served by a built-in kernel, and must still be right: a catalogue tree over streams of different widths, one
+    buffer under two stream names, a NaN scalar on the left of its product (the swap that makes the tree canonical would change
+    which NaN wins), operands of a subtraction swapped — all interpreted (expr_jit = 0), all equal to the oracle; and special
+    scalars ON the catalogue's path (inf, -0.0, NaN on the right) against the interpreter bit for bit."""
+    host, dev, m, dm = pool
+    P, L = ec.fused, ec.lib()
+    L.ec_tune_set(b"expr_jit", 0)
+    try:
+        ndvi = _FIXED["ndvi"][2][0]
+        affine_left = _FIXED["affine"][2][1]  # k0 * s0, k1 + r
+        cases = [([eco.U16, eco.F32], [], ndvi),                                        # widths differ
+                 ([eco.U16, eco.U16], [], [(eco.SUB, _S(1), _S(0), 0), (eco.ADD, _S(0), _S(1), 1), (eco.DIV, _R(0), _R(1), 0)]),  # another tree
+                 ([eco.F32], [float("nan"), 1.0], affine_left)]                          # NaN scalar on the left: not swapped
+        for cts, scalars, steps in cases:
+            bufs = [dev[ct].shard(k, N) for k, ct in enumerate(cts)]
+            hs = [host[ct][k:k + N] for k, ct in enumerate(cts)]
+            f0, i0 = _stat(ec, b"expr_fixed_launches"), _stat(ec, b"expr_interp_launches")
+            got = P.program(bufs, scalars, steps)
+            assert _stat(ec, b"expr_fixed_launches") == f0 and _stat(ec, b"expr_interp_launches") == i0 + 1, (cts, steps)
+            eo, loose = _oracle_program(hs, scalars, steps)
+            assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+        # one buffer as both streams of NDVI: (a - a) / (a + a)
+        a = dev[eco.I16].shard(0, N)
+        f0 = _stat(ec, b"expr_fixed_launches")
+        got = P.program([a, a], [], ndvi)
+        assert _stat(ec, b"expr_fixed_launches") == f0
+        eo, loose = _oracle_program([host[eco.I16][:N], host[eco.I16][:N]], [], ndvi)
+        assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+        # special scalars through the built-in kernels
+        for scalars in ([float("inf"), 1.0], [-0.0, float("-inf")], [2.0, float("nan")], [0.0, 0.0]):
+            for ct in (eco.F32, eco.F64, eco.U8, eco.I64):
+                x = dev[ct].shard(1, N)
+                f0 = _stat(ec, b"expr_fixed_launches")
+                got = P.program([x], scalars, _FIXED["affine"][2][0])
+                assert _stat(ec, b"expr_fixed_launches") == f0 + 1
+                L.ec_tune_set(b"expr_fixed", 0)
+                try:
+                    interp = P.program([x], scalars, _FIXED["affine"][2][0])
+                finally:
+                    L.ec_tune_set(b"expr_fixed", 1)
+                assert np.array_equal(bits_of(got.to_numpy()), bits_of(interp.to_numpy())), (scalars, ct)
+                eo, loose = _oracle_program([host[ct][1:1 + N]], scalars, _FIXED["affine"][2][0])
+                assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+    finally:
+        L.ec_tune_set(b"expr_jit", 1)
+
+
+@pytest.mark.gpu
+def test_expr_ahead_of_time_kernel_inside_a_stream_capture_and_from_lazy_trees(ec, pool):
+    """A catalogue program first met INSIDE a stream capture is recorded as its built-in kernel (the compiled form cannot be:
+    no module load in a capture), and the operator syntax reaches the same kernels: `2.5 * (n - r) / (n + 6.0 * r - 7.5 * b + 1.0)`
+    written with `lazy()` is one launch of the EVI kernel."""
+    import torch
+    host, dev, m, dm = pool
+    P, L, E = ec.fused, ec.lib(), ec._ffi
+    nir, red, blue = dev[eco.U16].shard(0, N), dev[eco.I16].shard(2, N), dev[eco.U16].shard(4, N)
+    hn, hr, hb = host[eco.U16][:N], host[eco.I16][2:2 + N], host[eco.U16][4:4 + N]
+    from erased_cells_hip.fused import lazy
+    f0 = _stat(ec, b"expr_fixed_launches")
+    got = (2.5 * (lazy(nir) - red) / (lazy(nir) + 6.0 * lazy(red) - 7.5 * lazy(blue) + 1.0)).eval()
+    assert _stat(ec, b"expr_fixed_launches") == f0 + 1
+    eo, loose = _oracle_program([hn, hr, hb], _FIXED["evi"][1], _FIXED["evi"][2][0])
+    assert_f64_bits_equal(got.to_numpy(), eo, nan_by_class_where=loose)
+    # inside a capture
+    out = ec.CellBuffer.empty(N, ec.Float64)
+    steps = _FIXED["evi"][2][1]
+    dt = (C.c_uint8 * 3)(eco.U16, eco.I16, eco.U16)
+    p = (C.c_void_p * 3)(nir.mem.ptr, red.mem.ptr, blue.mem.ptr)
+    sc = (E.EcValue * 4)(*[ec.CellValue.new(x).to_ec() for x in _FIXED["evi"][1]])
+    st = (E.EcExprStep * len(steps))(*[E.EcExprStep(op, a, b, dst) for op, a, b, dst in steps])
+    cap = torch.cuda.Stream()
+    E.check(L.ec_prepare_stream(cap.cuda_stream))
+    g = torch.cuda.CUDAGraph()
+    cap.wait_stream(torch.cuda.current_stream())
+    f0, i0 = _stat(ec, b"expr_fixed_launches"), _stat(ec, b"expr_interp_launches")
+    with torch.cuda.graph(g, stream=cap):
+        E.check(L.ec_expr(dt, p, 3, sc, 4, st, len(steps), N, out.mem.ptr, cap.cuda_stream))
+    assert _stat(ec, b"expr_fixed_launches") == f0 + 1 and _stat(ec, b"expr_interp_launches") == i0
+    g.replay()
+    torch.cuda.synchronize()
+    assert_f64_bits_equal(out.to_numpy(), eo, nan_by_class_where=loose)

@@ -622,3 +622,71 @@ def test_host_to_host_over_a_shard_group_on_the_fixtures(ec, golden_dir, G):
         bad = [(ec.ADD, S(0), R(3), 0)]
         with pytest.raises(Exception):
             g.program_host([nir_h, red_h], [], bad, rows, cols)
+
+
+_REFUSED_PIN_BODY = r'''
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import erased_cells_hip as ec
+from erased_cells_hip import sharded
+refuse, tmp = sys.argv[2] == "1", sys.argv[3]
+ec.init(0)
+rows, cols = 384, 1000
+n = rows * cols
+rng = np.random.default_rng(7)
+a = rng.integers(1, 60000, n, dtype=np.uint16)
+b = rng.integers(0, 200, n, dtype=np.uint8)
+a.tofile(tmp + "/a.bin")
+b.tofile(tmp + "/b.bin")
+ra = np.memmap(tmp + "/a.bin", dtype=np.uint16, mode="r")  # PROT_READ, file-backed
+rb = np.memmap(tmp + "/b.bin", dtype=np.uint8, mode="r")
+S, R = (lambda k: k), (lambda k: 4 + k)
+prog = [(ec.SUB, S(0), S(1), 0), (ec.ADD, S(0), S(1), 1), (ec.DIV, R(0), R(1), 0)]
+af, bf = a.astype(np.float64), b.astype(np.float64)
+exp = (af - bf) / (af + bf)
+L = ec.lib()
+ec._ffi.check(L.ec_tune_set(b"inject_pin_refusal", 1 if refuse else 0))
+one = ec.fused.program_host([ra, rb], [], prog, chunk_cells=50_000)
+assert np.array_equal(one.view(np.uint64), exp.view(np.uint64))
+for G in (1, 3):
+    with sharded.ShardGroup([0] * G, host_combine=G > 1) as g:
+        out = g.program_host([ra, rb], [], prog, rows, cols, chunk_cells=50_000)
+        assert np.array_equal(out.view(np.uint64), exp.view(np.uint64)), G
+        out, valid = g.program_host([ra, rb], [], prog, rows, cols, nodata=[None, 0], out_nodata=-1.0, want_mask=True, chunk_cells=50_000)
+        assert np.array_equal(valid, b != 0) and np.array_equal(out[valid].view(np.uint64), exp[valid].view(np.uint64))
+        assert np.all(out[~valid] == -1.0)
+        # chunk_cells = 0 takes the one-chunk form below 64 MiB: it enters its ranges with use_all and must pass a refused entry of its caller too
+        out = g.program_host([ra, rb], [], prog, rows, cols)
+        assert np.array_equal(out.view(np.uint64), exp.view(np.uint64)), G
+        # a nodata value of the wrong cell type is refused on the calling thread, before any page is locked
+        k = 2
+        dt = (C.c_uint8 * k)(ec.UInt16, ec.UInt8)
+        p = (C.c_void_p * k)(ra.ctypes.data, rb.ctypes.data)
+        wrong = ec.CellValue(ec.UInt16, 0).to_ec()
+        nd = (C.POINTER(ec._ffi.EcValue) * k)(C.POINTER(ec._ffi.EcValue)(), C.pointer(wrong))
+        st = (ec._ffi.EcExprStep * len(prog))(*[ec._ffi.EcExprStep(*q) for q in prog])
+        o = np.empty(n)
+        try:
+            ec._ffi.check(L.ec_sharded_host_expr(g.handle, dt, p, nd, k, None, 0, st, len(prog), rows, cols, o.ctypes.data, None, None, 50_000))
+            raise SystemExit("a nodata value of the wrong cell type was accepted")
+        except ec._ffi.EcError as e:
+            assert "nodata" in str(e), str(e)
+print("REFUSED-PIN OK")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("refuse", [False, True])
+def test_host_to_host_when_page_locking_is_refused(tmp_path, refuse):
+    """Host arrays the runtime will not page-lock — with `inject_pin_refusal` every array whatever its kind; without it a read-only
+    file mapping (`np.memmap(mode="r")`, which this runtime does register) — go through the host-to-host pipelines correctly, and above
+    all RETURNING.  Round 3 hung here: `ec_sharded_host_expr` entered the whole arrays as ranges in use after a refused registration,
+    and every shard's own pipeline (chunk_cells != 0, so it asks for a registration too) then waited for its caller's entry, forever,
+    at any shard count.  One pipeline (`ec_host_expr`), a group of one shard, a group of three; plain and masked.  In a process of its
+    own (a hang or an abort there fails this test and nothing else)."""
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "erased-cells_amd", "python")
+    r = subprocess.run([sys.executable, "-c", _REFUSED_PIN_BODY, pkg, "1" if refuse else "0", str(tmp_path)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "REFUSED-PIN OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

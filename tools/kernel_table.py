@@ -182,12 +182,16 @@ def main():
     evi = [(ec.SUB, S(0), S(1), 0), (ec.MUL, R(0), K(0), 0), (ec.MUL, S(1), K(1), 1), (ec.ADD, S(0), R(1), 1),
            (ec.MUL, S(2), K(2), 2), (ec.SUB, R(1), R(2), 1), (ec.ADD, R(1), K(3), 1), (ec.DIV, R(0), R(1), 0)]
     two = [(ec.ADD, S(0), S(1), 0), (ec.MUL, R(0), S(2), 0)]
-    for mode, how in ((0, "interpreted, k_expr"), (2, "compiled, ec_expr_jit")):
+    # three forms of the same program: the built-in straight-line kernel of the ahead-of-time catalogue (what runs by default for
+    # these two; expr_jit = 0 here, so nothing else can), the interpreter (expr_fixed = 0), the program compiled through hiprtc
+    for fixed, mode, how in ((1, 0, "built-in, k_expr_fixed; expr_jit = 0"), (0, 0, "interpreted, k_expr"), (0, 2, "compiled, ec_expr_jit")):
+        chk(L.ec_tune_set(b"expr_fixed", fixed))
         chk(L.ec_tune_set(b"expr_jit", mode))
         for label, prog in (("expr (a+b)*c UInt16 x3, 2 steps", two), ("expr EVI UInt16 x3, 8 steps, 4 scalars", evi)):
             st = (E.EcExprStep * len(prog))(*[E.EcExprStep(*q) for q in prog])
             bench(f"{label} ({how})", 2 + 2 + 2 + 8, lambda st=st, k=len(prog): chk(L.ec_expr(dt3e, p3e, 3, sce, 4, st, k, n, out64.mem.ptr, stream)))
     chk(L.ec_tune_set(b"expr_jit", 1))
+    chk(L.ec_tune_set(b"expr_fixed", 1))
 
     print(f"Per-kernel roofline table, {side}x{side} = {n} cells, one MI355X, HIP-event timed over >= 40 ms of launches after an "
           f"equal untimed ramp, peak {PEAK:.0f} GB/s, map_u={map_u}\n")

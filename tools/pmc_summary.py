@@ -33,6 +33,7 @@ WORKLOADS = {
     "binop_add_f32_f32": (16, 8, ["k_binop_direct"]),
     "evi_fused": (14, 6, ["k_expr"]),
     "evi_fused_compiled": (14, 6, ["ec_expr_jit"]),
+    "evi_fused_builtin": (14, 6, ["k_expr_fixed"]),
     "evi": (130, 66, ["k_binop_direct", "k_binop_scalar"]),
 }
 TRAFFIC_KEY = {"div": "binop_div_u8_u16"}
@@ -150,7 +151,7 @@ def main():
                           "(+ --kernel-trace) in separate passes over `python3 bench.py --workload ... --steps 5 --warmup 1 --ramp 0`, program "
                           "directly after `--`; FETCH_SIZE (KiB) x1024 x2 per MI355X_MICROARCH.md §HBM, WRITE_SIZE (KiB) x1024; totals over the "
                           "workload's kernels / 6 steps; request_counter_bytes: TCC_EA0_RDREQ/WRREQ by request size, no correction factor "
-                          "(tools/pmc_summary.py, tools/jobs/r03pmc.sh)"}
+                          "(tools/pmc_summary.py, tools/jobs/r03pmc.sh / r04pmc.sh)"}
         json.dump(cur, open(a.traffic, "w"), indent=1)
     return 0
 
