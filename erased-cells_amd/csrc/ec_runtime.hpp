@@ -52,7 +52,7 @@ struct Tuning {
                                    // program has interpreted 2^31 cell-steps, 2 on the calling thread at first sight
     std::atomic<int> expr_fixed{1};  // 1 (default): a program of the ahead-of-time catalogue (ec_expr_fixed.hpp) runs as its built-in straight-line
                                      // kernel; 0: never (the interpreter / the compiled form serve it — the comparison path of the tests)
-    std::atomic<int> write_lds_kb{64};  // LDS reserved per workgroup of a PURE-WRITE launch (fill, the generators): caps the workgroups resident
+    std::atomic<int> write_lds_kb{64};  // LDS reserved per workgroup of a PURE-WRITE launch (ec_fill): caps the workgroups resident
                                         // per CU (64 KiB: two of 160 KiB).  A write-only stream runs faster from few resident waves — 0.85 of the HBM
                                         // peak at full occupancy, 0.88-0.90 at 2-3 workgroups per CU, 0.93 with write-through stores on top
                                         // (profiles/r04/tune_store_v2.log); any launch that also loads needs its occupancy and gets none.  0 = no cap
