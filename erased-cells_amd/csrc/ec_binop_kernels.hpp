@@ -24,6 +24,10 @@
 
 #include "ec_device.hpp"
 
+#ifndef EC_DIV_STAGE
+#define EC_DIV_STAGE 2  // build-time A/B switch of the short divide's tile code: 1 = the tile's 2 U quotients staged together, 2 = chunk by chunk (default)
+#endif
+
 namespace ecd {
 
 constexpr int kBlock = 256;          // 4 waves
@@ -80,10 +84,32 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
             // (integer compares), and only a wave that holds a zero divisor runs the selects — 5 of the 11 vector instructions
             // per cell off the common path (with the u8 operand served from the Infinity Cache the divide is no longer fully
             // hidden behind memory: 0.4222 ms against the add's 0.4134 before this, profiles/r03/kernel_table.md)
-            // stage by stage over the tile's 2 U cells, not cell by cell: each quotient is a chain of six dependent FP64 instructions,
-            // and written cell by cell the compiler issues the chains one after the other (≈ 300 cycles in which the wave has no
-            // second instruction to offer: the divide ran 2 % behind the add at equal bytes, profiles/r04/bench_store_policy_ab.md);
-            // staged, the 2 U chains overlap
+            // Each quotient is a chain of six dependent FP64 instructions; written cell by cell the compiler issues the chains one
+            // after the other, and with the u8 operand coming from HBM too the kernel is bound by how long a workgroup lives (its
+            // occupancy is the hardware's maximum), so those ≈ 300 cycles show: the divide ran 2 % behind the add at equal bytes
+            // (0.816 against 0.832, profiles/r04/store_policy_ab/).  Interleaved, rotating operand sets, three runs each: all 2 U
+            // chains staged together 0.819-0.823; chunk by chunk 0.827 (the add: 0.8335).
+#if EC_DIV_STAGE == 2
+            // chunk by chunk — the chunk's two chains staged, its zero test, its store — so that the first store leaves as soon as
+            // the first chunk's loads are back, while the second chunk's may still be in flight
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                double av[2], bv[2], q[2], y[2], e[2];
+                bool zero = false;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    av[k] = to_f64(a[j][k]);
+                    bv[k] = to_f64(b[j][k]);
+                    zero = zero || b[j][k] == 0;
+                }
+                div_small_int_nonzero_staged<2>(av, bv, q, y, e);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(zero) != 0, 0)) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) q[i] = bv[i] == 0.0 ? div_by_zero(av[i]) : q[i];
+                }
+                store_vec<NT_ST>(op + base + size_t(j) * kBlock, D2{q[0], q[1]});
+            }
+#else
             double av[2 * U], bv[2 * U], q[2 * U], y[2 * U], e[2 * U];
             bool zero = false;
 #pragma unroll
@@ -101,6 +127,7 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
             }
 #pragma unroll
             for (int j = 0; j < U; ++j) store_vec<NT_ST>(op + base + size_t(j) * kBlock, D2{q[2 * j], q[2 * j + 1]});
+#endif
         } else {
 #pragma unroll
             for (int j = 0; j < U; ++j) {

@@ -179,15 +179,34 @@ __global__ __launch_bounds__(kBlock) void k_expr_fixed(ExprArgs ea, FixedMap fm,
                 for (int k = 0; k < NS; ++k) q[k][j] = nt_load(b[k] + pr);
         }
     }
+    constexpr int last = P::steps[P::nsteps - 1].dst;
+    // Long programs run chunk by chunk (the pair of cells of one store): a chunk's steps run and its store leaves as soon as the chunk's
+    // loads are back, while the next chunk's may still be in flight — EVI 0.797 against 0.789 over the tile's four cells at once; the two-
+    // and three-step programs lose half a point that way (fewer independent chains per step) and run over the whole tile
+    // (profiles/r04/fixed_chunked_ab.md).
+    if constexpr (P::nsteps > 3) {
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        double s[kExprMaxStreams][2] = {}, r[kExprRegs][2];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const Raw one[1] = {q[k][j]};
+            widen_pairs<C, 1>(one, kind[k], s[k]);
+        }
+        fixed_run<P, C, 2>(s, sc, r);
+        const size_t pr = base + size_t(j) * kBlock;
+        if (full || pr < npairs) nt_store(D2{r[last][0], r[last][1]}, op + pr);
+    }
+    } else {
     double s[kExprMaxStreams][NC] = {}, r[kExprRegs][NC];
 #pragma unroll
     for (int k = 0; k < NS; ++k) widen_pairs<C, U>(q[k], kind[k], s[k]);
     fixed_run<P, C, NC>(s, sc, r);
-    constexpr int last = P::steps[P::nsteps - 1].dst;
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         const size_t pr = base + size_t(j) * kBlock;
         if (full || pr < npairs) nt_store(D2{r[last][2 * j], r[last][2 * j + 1]}, op + pr);
+    }
     }
     if (blockIdx.x == 0 && threadIdx.x < 2) {  // the peeled head cell (lane 0) and the odd tail cell (lane 1)
         const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;

@@ -141,6 +141,82 @@ __host__ __device__ constexpr int fused_any_min_class(int a, int b, int c, int d
 //   is_sc[k]  slot k is the scalar sc[k]
 //   small     every slot is a buffer of ≤16-bit integer cells and the chain has the NDVI shape (x ± y) / (z ± w | z):
 //             the 2-add + 6-instruction exact divide of ec_fused_kernels.hpp (proven on the whole operand square)
+#ifndef EC_FUSED_CHUNKED
+#define EC_FUSED_CHUNKED 0  // build-time A/B switch: 1 = the expression runs chunk by chunk with each chunk's store right behind it
+#endif
+
+// (x o1 y) o2 (z o3 w) for the 2 NP cells of NP loaded pairs per slot: widening by launch-uniform kind, class-0 slots filled from an earlier
+// slot or a scalar, the ops as wave-uniform switches around the cells.
+template <int CX, int CY, int CZ, int CW, int NP>
+__device__ __forceinline__ void fused_any_cells(const FusedArgs& fa, const typename raw_pair<CX>::type (&rx)[NP], const typename raw_pair<CY>::type (&ry)[NP],
+                                                const typename raw_pair<CZ>::type (&rz)[NP], const typename raw_pair<CW>::type (&rw)[NP], bool has_w,
+                                                double (&o)[2 * NP]) {
+    constexpr int NC = 2 * NP;
+    double vx[NC], vy[NC];
+    if constexpr (CX != 0) widen_pairs<CX, NP>(rx, fa.dt[0] >> 2, vx);
+    else {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) vx[i] = fa.sc[0];
+    }
+    if constexpr (CY != 0) widen_pairs<CY, NP>(ry, fa.dt[1] >> 2, vy);
+    else {
+        const bool from_x = !fa.is_sc[1];  // a class-0 slot that is not a scalar is an alias; slot 1 can only alias slot 0
+#pragma unroll
+        for (int i = 0; i < NC; ++i) vy[i] = from_x ? vx[i] : fa.sc[1];
+    }
+    if (fa.small) {  // launch-uniform: NDVI shape on ≤16-bit integer cells (no scalar operand)
+        double vz[NC], vw[NC];
+        if constexpr (CZ != 0) widen_pairs<CZ, NP>(rz, fa.dt[2] >> 2, vz);
+        else {
+            const int a = fa.alias[2];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) vz[i] = a == 0 ? vx[i] : vy[i];
+        }
+        if constexpr (CW != 0) widen_pairs<CW, NP>(rw, fa.dt[3] >> 2, vw);
+        else {
+            const int a = fa.alias[3];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) vw[i] = a == 0 ? vx[i] : a == 1 ? vy[i] : vz[i];
+        }
+        // x - y == x + (-y) exactly; the sign flips are launch-uniform
+        const uint64_t f1 = fa.o1 == EC_SUB ? 0x8000000000000000ull : 0ull;
+        const uint64_t f3 = fa.o3 == EC_SUB ? 0x8000000000000000ull : 0ull;
+        double t1[NC], t2[NC], y[NC], e[NC];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            t1[i] = vx[i] + bits_f64(f64_bits(vy[i]) ^ f1);
+            t2[i] = has_w ? vz[i] + bits_f64(f64_bits(vw[i]) ^ f3) : vz[i];
+        }
+        div_small_int_nonzero_staged<NC>(t1, t2, o, y, e);  // the NC chains of six dependent instructions overlap
+#pragma unroll
+        for (int i = 0; i < NC; ++i) o[i] = t2[i] == 0.0 ? div_by_zero(t1[i]) : o[i];
+    } else {
+        double t1[NC], t2[NC];
+        apply_tile<NC>(fa.o1, vx, vy, t1);
+        double vz[NC];
+        if constexpr (CZ != 0) widen_pairs<CZ, NP>(rz, fa.dt[2] >> 2, vz);
+        else {
+            const int a = fa.is_sc[2] ? 2 : fa.alias[2];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) vz[i] = a == 0 ? vx[i] : a == 1 ? vy[i] : fa.sc[2];
+        }
+        if (has_w) {
+            double vw[NC];
+            if constexpr (CW != 0) widen_pairs<CW, NP>(rw, fa.dt[3] >> 2, vw);
+            else {
+                const int a = fa.is_sc[3] ? 3 : fa.alias[3];
+#pragma unroll
+                for (int i = 0; i < NC; ++i) vw[i] = a == 0 ? vx[i] : a == 1 ? vy[i] : a == 2 ? vz[i] : fa.sc[3];
+            }
+            apply_tile<NC>(fa.o3, vz, vw, t2);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) t2[i] = vz[i];
+        }
+        apply_tile<NC>(fa.o2, t1, t2, o);
+    }
+}
+
 template <int CX, int CY, int CZ, int CW>
 __global__ __launch_bounds__(kBlock) void k_fused_any(FusedArgs fa, double* __restrict__ out, uint8_t* __restrict__ out_mask, size_t n) {
     constexpr int U = fused_u(size_t(fused_any_min_class(CX, CY, CZ, CW)));  // pairs per lane per tile (2: ec_fused_kernels.hpp)
@@ -195,71 +271,31 @@ __global__ __launch_bounds__(kBlock) void k_fused_any(FusedArgs fa, double* __re
             }
         }
     }
-    double vx[NC], vy[NC], o[NC];
-    if constexpr (CX != 0) widen_pairs<CX, U>(rx, fa.dt[0] >> 2, vx);
-    else {
+    // Over the tile's 2 U cells at once.  (EC_FUSED_CHUNKED 1: chunk by chunk — the pair of cells of one 16-byte store — with each chunk's store
+    // right behind it, the form that gained 0.5-1 % in k_binop_direct's short divide and in the built-in EVI kernel.  Here it gains nothing
+    // that exceeds the run-to-run spread: NDVI u16 0.824 / 0.824 against 0.829 / 0.809, NDVI u16 + f32 0.8225 / 0.8255 against 0.8145 /
+    // 0.8253, config 3 fused 0.744 / 0.770 against 0.767 / 0.766; profiles/r04/fixed_chunked_ab.md.)
+#if EC_FUSED_CHUNKED
 #pragma unroll
-        for (int i = 0; i < NC; ++i) vx[i] = fa.sc[0];
+    for (int j = 0; j < U; ++j) {
+        const typename raw_pair<CX>::type x1[1] = {rx[j]};
+        const typename raw_pair<CY>::type y1[1] = {ry[j]};
+        const typename raw_pair<CZ>::type z1[1] = {rz[j]};
+        const typename raw_pair<CW>::type w1[1] = {rw[j]};
+        double o[2];
+        fused_any_cells<CX, CY, CZ, CW, 1>(fa, x1, y1, z1, w1, has_w, o);
+        const size_t pr = base + size_t(j) * kBlock;
+        if (full || pr < npairs) nt_store(D2{o[0], o[1]}, op + pr);
     }
-    if constexpr (CY != 0) widen_pairs<CY, U>(ry, fa.dt[1] >> 2, vy);
-    else {
-        const bool from_x = !fa.is_sc[1];  // a class-0 slot that is not a scalar is an alias; slot 1 can only alias slot 0
-#pragma unroll
-        for (int i = 0; i < NC; ++i) vy[i] = from_x ? vx[i] : fa.sc[1];
-    }
-    if (fa.small) {  // launch-uniform: NDVI shape on ≤16-bit integer cells (no scalar operand)
-        double vz[NC], vw[NC];
-        if constexpr (CZ != 0) widen_pairs<CZ, U>(rz, fa.dt[2] >> 2, vz);
-        else {
-            const int a = fa.alias[2];
-#pragma unroll
-            for (int i = 0; i < NC; ++i) vz[i] = a == 0 ? vx[i] : vy[i];
-        }
-        if constexpr (CW != 0) widen_pairs<CW, U>(rw, fa.dt[3] >> 2, vw);
-        else {
-            const int a = fa.alias[3];
-#pragma unroll
-            for (int i = 0; i < NC; ++i) vw[i] = a == 0 ? vx[i] : a == 1 ? vy[i] : vz[i];
-        }
-        // x - y == x + (-y) exactly; the sign flips are launch-uniform
-        const uint64_t f1 = fa.o1 == EC_SUB ? 0x8000000000000000ull : 0ull;
-        const uint64_t f3 = fa.o3 == EC_SUB ? 0x8000000000000000ull : 0ull;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const double t1 = vx[i] + bits_f64(f64_bits(vy[i]) ^ f1);
-            const double t2 = has_w ? vz[i] + bits_f64(f64_bits(vw[i]) ^ f3) : vz[i];
-            o[i] = div_small_int(t1, t2);
-        }
-    } else {
-        double t1[NC], t2[NC];
-        apply_tile<NC>(fa.o1, vx, vy, t1);
-        double vz[NC];
-        if constexpr (CZ != 0) widen_pairs<CZ, U>(rz, fa.dt[2] >> 2, vz);
-        else {
-            const int a = fa.is_sc[2] ? 2 : fa.alias[2];
-#pragma unroll
-            for (int i = 0; i < NC; ++i) vz[i] = a == 0 ? vx[i] : a == 1 ? vy[i] : fa.sc[2];
-        }
-        if (has_w) {
-            double vw[NC];
-            if constexpr (CW != 0) widen_pairs<CW, U>(rw, fa.dt[3] >> 2, vw);
-            else {
-                const int a = fa.is_sc[3] ? 3 : fa.alias[3];
-#pragma unroll
-                for (int i = 0; i < NC; ++i) vw[i] = a == 0 ? vx[i] : a == 1 ? vy[i] : a == 2 ? vz[i] : fa.sc[3];
-            }
-            apply_tile<NC>(fa.o3, vz, vw, t2);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NC; ++i) t2[i] = vz[i];
-        }
-        apply_tile<NC>(fa.o2, t1, t2, o);
-    }
+#else
+    double o[NC];
+    fused_any_cells<CX, CY, CZ, CW, U>(fa, rx, ry, rz, rw, has_w, o);
 #pragma unroll
     for (int j = 0; j < U; ++j) {
         const size_t pr = base + size_t(j) * kBlock;
         if (full || pr < npairs) nt_store(D2{o[2 * j], o[2 * j + 1]}, op + pr);
     }
+#endif
     if (blockIdx.x == 0 && threadIdx.x < 2) {  // the peeled head cell (lane 0) and the odd tail cell (lane 1)
         const bool do_it = threadIdx.x == 0 ? head != 0 : ((n - head) & 1) != 0;
         const size_t i = threadIdx.x == 0 ? 0 : n - 1;

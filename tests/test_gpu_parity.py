@@ -539,6 +539,30 @@ def test_tuning_knobs_do_not_change_results(ec, map_u, reduce_bpc, reduce_shape)
         L.ec_tune_set(b"reduce_shape", 0)
 
 
+def test_fill_under_every_occupancy_cap(ec):
+    """`ec_fill` reserves unused LDS so that few workgroups per CU write (`write_lds_kb`, 64 KiB by default: two per CU); the knob changes
+    the launch, never the cells — every cap, every cell width, ragged lengths, odd window offsets; and the knob reads back."""
+    import ctypes as C
+    L = ec.lib()
+    v = C.c_int64(0)
+    assert L.ec_stat_get(b"tune.write_lds_kb", C.byref(v)) == 0 and v.value == 64
+    try:
+        for kb in (0, 16, 48, 64, 1000):  # clamped to 64
+            assert L.ec_tune_set(b"write_lds_kb", kb) == 0
+            assert L.ec_stat_get(b"tune.write_lds_kb", C.byref(v)) == 0 and v.value == min(kb, 64)
+            for ct, x in ((ec.UInt8, 201), (ec.Int16, -12345), (ec.Float32, 2.5), (ec.Float64, -0.0), (ec.UInt64, 2**63 + 5)):
+                for n, off in ((100_003, 0), (4096, 3), (1, 0)):
+                    big = ec.CellBuffer.fill(n + 8, ec.CellValue(ct, 0))
+                    w = big.shard(off, n)
+                    ec._ffi.check(L.ec_fill(ct, w.mem.ptr, n, C.byref(ec.CellValue(ct, x).to_ec()), ec.stream()))
+                    got = big.to_numpy()
+                    exp = np.zeros(n + 8, dtype=ec.NP_DTYPES[ct])
+                    exp[off:off + n] = x
+                    assert np.array_equal(bits_of(got), bits_of(exp)), (kb, ct, n, off)
+    finally:
+        L.ec_tune_set(b"write_lds_kb", 64)
+
+
 def test_streams_threads_and_graph_capture(ec):
     """Re-entrancy: concurrent host threads on distinct streams (per-stream reduction scratch, per-thread
     device binding), and a chain of asynchronous calls captured into a hipGraph and replayed."""

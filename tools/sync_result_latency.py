@@ -25,10 +25,11 @@ for n in (186 * 169, 16384 * 16384):
              "mask_counts": lambda: chk(L.ec_mask_counts(m.mem.ptr, n, C.byref(t), C.byref(f), None)),
              "first_difference": lambda: chk(L.ec_first_difference(ec.UInt16, a.mem.ptr, b.mem.ptr, n, C.byref(idx), None))}
     for name, fn in calls.items():
-        for _ in range(200):
-            fn()
-        reps = 2000 if n < 1 << 20 else 300
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        print(f"{'zero-copy' if not os.environ.get('EC_NO_ZERO_COPY_RESULTS') else 'copy     '}  n={n:>10}  {name:17s} {(time.perf_counter() - t0) / reps * 1e6:8.1f} us per call")
+        for spin in (0,):  # (round 4 tried polling the stream with hipStreamQuery for up to 200 µs before blocking: slower, removed)
+            for _ in range(200):
+                fn()
+            reps = 2000 if n < 1 << 20 else 300
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            print(f"{'zero-copy' if not os.environ.get('EC_NO_ZERO_COPY_RESULTS') else 'copy     '}  n={n:>10}  {name:17s} sync_spin_us={spin:3d} {(time.perf_counter() - t0) / reps * 1e6:8.1f} us per call")
