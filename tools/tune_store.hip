@@ -157,6 +157,40 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_wide(const uint8_t* __restri
     }
 }
 
+// Where a wave's life goes: the shipped mix tile with four timestamps per wave (s_memrealtime, 100 MHz) — start, operands back (first use),
+// stores issued, stores acknowledged (s_waitcnt vmcnt(0)) — written for one wave in 64.  The kernel is bound by how long a workgroup lives
+// (its occupancy is the hardware's maximum): this says which part of that life is load latency and which is the wait for the stores.
+template <int POL>
+__global__ __launch_bounds__(256) void k_mix_timed(const uint8_t* __restrict__ l, const uint16_t* __restrict__ r, D2* __restrict__ op, size_t tiles,
+                                                   unsigned* __restrict__ stats) {
+    const unsigned long long t0 = wall_clock64();
+    const size_t b = blockIdx.x, tile = (b & 1) ? tiles - 1 - (b >> 1) : (b >> 1);
+    const size_t base = tile * 512 + threadIdx.x;
+    cells<uint8_t, 2> a[2];
+    cells<uint16_t, 2> c[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        a[j] = load_cells<true, uint8_t, 2>(l + 2 * (base + j * 256));
+        c[j] = load_cells<true, uint16_t, 2>(r + 2 * (base + j * 256));
+    }
+    D2 o[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o[j] = D2{to_f64(a[j][0]) + to_f64(c[j][0]), to_f64(a[j][1]) + to_f64(c[j][1])};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = wall_clock64();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) store16<POL>(op + base + j * 256, o[j]);
+    const unsigned long long t2 = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t3 = wall_clock64();
+    if ((b & 63) == 0 && (threadIdx.x & 63) == 0) {
+        unsigned* q = stats + ((b >> 6) * 4 + (threadIdx.x >> 6)) * 3;
+        q[0] = unsigned(t1 - t0);
+        q[1] = unsigned(t2 - t1);
+        q[2] = unsigned(t3 - t2);
+    }
+}
+
 // persistent workgroups.  WALK 0: grid-stride (tile = b + k * grid)   1: workgroup b walks its own contiguous range
 //                         2: the workgroups of an XCD (b % 8) walk that XCD's eighth, stride = grid / 8
 template <int U, int WAVES, bool WC, int POL, int WALK, bool MIX>
@@ -489,6 +523,38 @@ int main(int argc, char** argv) {
             RD_PERS(512, 4, 4)
             RD_PERS(1024, 8, 2)
         }
+    }
+    if (only && !strcmp(only, "wave-life")) {
+        // not a variant: a one-off measurement, printed and done
+        const size_t tiles = npairs / 512;
+        unsigned* stats;
+        const size_t nst = (tiles / 64 + 1) * 4 * 3;
+        CK(hipMalloc(&stats, nst * 4));
+        for (int pol : {1, 4}) {
+            CK(hipMemset(stats, 0, nst * 4));
+            for (int i = 0; i < 40; ++i) {
+                if (pol == 1) k_mix_timed<1><<<unsigned(tiles), 256>>>(a[i % SETS], b[i % SETS], (D2*)out[i & 1], tiles, stats);
+                else k_mix_timed<4><<<unsigned(tiles), 256>>>(a[i % SETS], b[i % SETS], (D2*)out[i & 1], tiles, stats);
+            }
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned> h(nst);
+            CK(hipMemcpy(h.data(), stats, nst * 4, hipMemcpyDeviceToHost));
+            double sum[3] = {0, 0, 0};
+            std::vector<unsigned> col[3];
+            size_t cnt = 0;
+            for (size_t w = 0; w + 2 < nst; w += 3) {
+                if (h[w] == 0 && h[w + 1] == 0 && h[w + 2] == 0) continue;
+                for (int k = 0; k < 3; ++k) { sum[k] += h[w + k]; col[k].push_back(h[w + k]); }
+                ++cnt;
+            }
+            printf("wave life, mix with %s stores (%zu waves sampled in the last launch; units of 10 ns):\n", polname[pol], cnt);
+            const char* what[3] = {"start -> operands back", "operands back -> stores issued", "stores issued -> stores acknowledged"};
+            for (int k = 0; k < 3; ++k) {
+                std::sort(col[k].begin(), col[k].end());
+                printf("  %-38s mean %7.1f  median %6u  p10 %6u  p90 %6u\n", what[k], sum[k] / cnt, col[k][cnt / 2], col[k][cnt / 10], col[k][cnt * 9 / 10]);
+            }
+        }
+        return 0;
     }
     if (vs.empty()) {
         fprintf(stderr, "no variant matches '%s'\n", only ? only : "");
