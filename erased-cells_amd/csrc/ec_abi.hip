@@ -587,11 +587,18 @@ extern "C" ec_status ec_mask_counts_device(const uint8_t* m, size_t n, uint64_t*
         if (tiles < 1) tiles = 1;
         grid = static_cast<unsigned>(tiles < size_t(cap) ? tiles : size_t(cap));
         uint64_t* direct = grid == 1 ? counts2_dev : nullptr;  // one workgroup: it writes the result itself
+        // more workgroups: the last one to add its count to the stream's accumulator word writes the result (one launch) — for masks below
+        // 2^29 cells.  Measured, rotating masks, every byte from HBM (profiles/r04/mask_counts_one_launch.md): 4096² 9.5 -> 7.5 µs, 16384²
+        // 49.5 -> 47.7 µs, but 32768² 158.4 -> 166.7 µs: the 1,024 returning atomics on one address queue behind the channel's reads when
+        // every workgroup is still streaming a gigabyte.  Big masks keep the finalize launch, which they do not feel (2 %); knob
+        // `counts_one_launch`: 0 never, 1 (default) below 2^29 cells, 2 always (below 2^40: ticket and sum share a 64-bit word).
+        const int one = tuning().counts_one_launch.load();
+        uint64_t* acc = (!direct && ((one == 1 && n < (size_t(1) << 29)) || (one >= 2 && n < (size_t(1) << 40)))) ? reinterpret_cast<uint64_t*>(sc.dev_acc()) : nullptr;
         const size_t stream_bytes[1] = {n};
         k_mask_count_partials<kReduceU><<<grid, kRBlock, 0, S(stream)>>>(m, n, reinterpret_cast<uint64_t*>(sc.dev), al,
-                                                                        head | (cache_plan(stream_bytes, 1) << 8), direct);
+                                                                        head | (cache_plan(stream_bytes, 1) << 8), direct, acc, counts2_dev);
         st = check_launch("mask_counts(partials)");
-        if (st != EC_OK || direct) return st;
+        if (st != EC_OK || direct || acc) return st;
     }
     k_mask_count_finalize<<<1, kFinalizeBlock, 0, S(stream)>>>(reinterpret_cast<const uint64_t*>(sc.dev), static_cast<int>(grid), n, counts2_dev);
     return check_launch("mask_counts(finalize)");

@@ -443,7 +443,8 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 template <int U>
 __global__ __launch_bounds__(kRBlock) void k_mask_count_partials(const uint8_t* __restrict__ m, size_t n,
                                                                 uint64_t* __restrict__ partials, bool aligned, unsigned head,
-                                                                uint64_t* __restrict__ counts2_if_single) {
+                                                                uint64_t* __restrict__ counts2_if_single, uint64_t* __restrict__ acc_or_null,
+                                                                uint64_t* __restrict__ counts2_if_acc) {
     const uint64_t n_total = n;
     uint64_t cnt = 0;
     const bool cacheable = ((head >> 8) & 1u) != 0;  // load policy of the launch (see k_min_max_partials)
@@ -498,6 +499,18 @@ __global__ __launch_bounds__(kRBlock) void k_mask_count_partials(const uint8_t* 
         if (counts2_if_single) {  // one-workgroup grid: this IS the result (see k_min_max_partials)
             counts2_if_single[0] = cnt;
             counts2_if_single[1] = n_total - cnt;
+        } else if (acc_or_null) {
+            // One launch (round 4): ticket and sum share one 64-bit word — every workgroup adds (1 << 40 | its count) with ONE returning
+            // device-scope atomic; the workgroup that finds grid - 1 tickets before it has just completed the sum, writes the result and
+            // leaves the word at zero for the next kernel on this stream.  A sum is order-free: the result is deterministic.  (The host
+            // passes acc only for n < 2^40; min / max do not pack with a ticket, so k_min_max_* keep their finalize launch.)
+            const uint64_t old = __hip_atomic_fetch_add(acc_or_null, (1ull << 40) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((old >> 40) == gridDim.x - 1u) {
+                const uint64_t total = (old & ((1ull << 40) - 1)) + cnt;
+                counts2_if_acc[0] = total;
+                counts2_if_acc[1] = n_total - total;
+                __hip_atomic_store(acc_or_null, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             partials[blockIdx.x] = cnt;
         }

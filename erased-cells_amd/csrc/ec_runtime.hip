@@ -169,8 +169,11 @@ ec_status get_scratch(hipStream_t s, Scratch* out) {
         ScratchEntry e;
         auto own = std::make_shared<ScratchOwner>();
         own->device = t_active;
-        ec_status st = check_hip(hipMalloc(reinterpret_cast<void**>(&own->dev), (2 * kMaxReduceBlocks + 4) * sizeof(int64_t)),
+        ec_status st = check_hip(hipMalloc(reinterpret_cast<void**>(&own->dev), (2 * kMaxReduceBlocks + 8) * sizeof(int64_t)),
                                  "hipMalloc(scratch)");
+        if (st != EC_OK) return st;
+        // the accumulator words (Scratch::dev_acc) start at zero; every kernel that uses one leaves it at zero again
+        st = check_hip(hipMemset(own->dev + 2 * kMaxReduceBlocks, 0, 8 * sizeof(int64_t)), "hipMemset(scratch)");
         if (st != EC_OK) return st;
         st = check_hip(hipHostMalloc(reinterpret_cast<void**>(&own->host), 4 * sizeof(int64_t), hipHostMallocDefault),
                        "hipHostMalloc(scratch)");
@@ -474,6 +477,7 @@ extern "C" ec_status ec_stat_get(const char* key, int64_t* value) {
         else if (!std::strcmp(k, "expr_jit")) *value = g_tuning.expr_jit;
         else if (!std::strcmp(k, "expr_fixed")) *value = g_tuning.expr_fixed;
         else if (!std::strcmp(k, "write_lds_kb")) *value = g_tuning.write_lds_kb;
+        else if (!std::strcmp(k, "counts_one_launch")) *value = g_tuning.counts_one_launch;
         else if (!std::strcmp(k, "cache_force")) *value = g_tuning.cache_force;
         else if (!std::strcmp(k, "pool_keep_mb")) *value = g_tuning.pool_keep_mb;
         else return set_error(EC_ERR_ARG, "ec_stat_get: unknown knob '%s'", k);
@@ -508,6 +512,7 @@ extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     else if (!std::strcmp(key, "inject_pin_refusal")) g_tuning.inject_pin_refusal = value != 0;
     else if (!std::strcmp(key, "expr_fixed")) g_tuning.expr_fixed = value != 0;
     else if (!std::strcmp(key, "write_lds_kb")) g_tuning.write_lds_kb = value < 0 ? 0 : value > 64 ? 64 : static_cast<int>(value);
+    else if (!std::strcmp(key, "counts_one_launch")) g_tuning.counts_one_launch = value < 0 ? 0 : value > 2 ? 2 : static_cast<int>(value);
     else if (!std::strcmp(key, "cache_force")) g_tuning.cache_force = value < 0 ? -1 : static_cast<int>(value);
     else if (!std::strcmp(key, "expr_jit")) g_tuning.expr_jit = value < 0 ? 0 : value > 2 ? 2 : static_cast<int>(value);
     else if (!std::strcmp(key, "pool_keep_mb")) {

@@ -56,6 +56,10 @@ struct Tuning {
                                         // per CU (64 KiB: two of 160 KiB).  A write-only stream runs faster from few resident waves — 0.85 of the HBM
                                         // peak at full occupancy, 0.88-0.90 at 2-3 workgroups per CU, 0.93 with write-through stores on top
                                         // (profiles/r04/tune_store_v2.log); any launch that also loads needs its occupancy and gets none.  0 = no cap
+    std::atomic<int> counts_one_launch{1};  // Mask::counts in ONE launch: every workgroup adds (1 << 40 | its count) to one 64-bit word of the stream's
+                                            // scratch with a returning atomic, the workgroup that reads grid - 1 in the upper bits owns the total,
+                                            // writes the result and zeroes the word — one device-scope round trip behind the last load instead of a
+                                            // second launch (0: partials + finalize kernel, the form of rounds 1-3; 1: below 2^29 cells; 2: always)
     std::atomic<int> cache_force{-1};  // A/B hook: >= 0 replaces cache_plan()'s answer by these bits for every launch (profiles/r04/cache_plan_ab.md)
     std::atomic<int64_t> pool_keep_mb{32768};  // release threshold of the library's stream-ordered pool (per device)
 };
@@ -165,12 +169,13 @@ struct Scratch {
                                           // stream's entry only drops the TABLE's reference, so a host thread that is
                                           // inside ec_min_max / ec_mask_counts / ec_first_difference with this scratch
                                           // (its `mu` locked, its kernels queued) keeps valid memory until it returns
-    int64_t* dev = nullptr;    // 2*kMaxReduceBlocks partials + 4 result words
+    int64_t* dev = nullptr;    // 2*kMaxReduceBlocks partials + 4 result words + 4 accumulator words (zero between kernels)
     int64_t* host = nullptr;   // 4 words, pinned (coherent): the synchronous-result entry points let the last kernel write
                                // its result straight into them — no device-to-host copy is queued behind the kernel
     int64_t* host_dev = nullptr;  // the same words as the device addresses them
     std::mutex* mu = nullptr;
     int64_t* dev_result() const { return dev + 2 * kMaxReduceBlocks; }
+    int64_t* dev_acc() const { return dev + 2 * kMaxReduceBlocks + 4; }
 };
 ec_status get_scratch(hipStream_t s, Scratch* out);
 

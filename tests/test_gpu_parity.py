@@ -539,6 +539,62 @@ def test_tuning_knobs_do_not_change_results(ec, map_u, reduce_bpc, reduce_shape)
         L.ec_tune_set(b"reduce_shape", 0)
 
 
+def test_mask_counts_in_one_launch_equals_two_launches_and_the_oracle(ec):
+    """`Mask::counts` (src/masked/mask.rs:72-80) in ONE launch — every workgroup adds (1 << 40 | its count) to a word of the stream's
+    scratch, the last one writes the result and zeroes the word — against the partials + finalize form (`counts_one_launch` = 0) and the
+    oracle: sizes around the one-workgroup boundary and far beyond it, odd window offsets, call after call on one stream (the word must be
+    back at zero every time), two streams from two threads, and a hipGraph replayed three times."""
+    import ctypes as C
+    import threading
+    import torch
+    L, E = ec.lib(), ec._ffi
+    rng = np.random.default_rng(11)
+    big = (rng.random(9_000_011) < 0.37).astype(np.uint8)
+    dbig = ec.Mask.new(big)
+    try:
+        for n, off in ((1, 0), (4096, 0), (65_536, 0), (65_537, 1), (131_073, 3), (1_000_003, 5), (9_000_000, 7)):
+            want = (int(big[off:off + n].sum()), n - int(big[off:off + n].sum()))
+            assert eco.mask_counts(big[off:off + n]) == want
+            for mode in (1, 0, 2, 2):
+                E.check(L.ec_tune_set(b"counts_one_launch", mode))
+                assert dbig.shard(off, n).counts() == want, (n, off, mode)
+        E.check(L.ec_tune_set(b"counts_one_launch", 2))
+        # two host threads, each on its own stream (each stream has its own accumulator word)
+        errs = []
+
+        def worker(k):
+            try:
+                s = C.c_void_p()
+                E.check(L.ec_stream_create(C.byref(s)))
+                t, f = C.c_uint64(), C.c_uint64()
+                for i in range(40):
+                    n = 2_000_000 + 13 * i + k
+                    E.check(L.ec_mask_counts(dbig.mem.ptr + k, n, C.byref(t), C.byref(f), s))
+                    assert (t.value, f.value) == (int(big[k:k + n].sum()), n - int(big[k:k + n].sum()))
+                E.check(L.ec_stream_destroy(s))
+            except BaseException as e:  # noqa: BLE001
+                errs.append(repr(e))
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for t_ in ths: t_.start()
+        for t_ in ths: t_.join()
+        assert not errs, errs
+        # captured: the kernel zeroes its word itself, so a replay finds it as the capture did
+        cap = torch.cuda.Stream()
+        E.check(L.ec_prepare_stream(cap.cuda_stream))
+        out = torch.zeros(2, dtype=torch.int64, device="cuda")
+        g = torch.cuda.CUDAGraph()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=cap):
+            E.check(L.ec_mask_counts_device(dbig.mem.ptr, 5_000_000, out.data_ptr(), cap.cuda_stream))
+        for _ in range(3):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert out.tolist() == [int(big[:5_000_000].sum()), 5_000_000 - int(big[:5_000_000].sum())]
+    finally:
+        E.check(L.ec_tune_set(b"counts_one_launch", 1))
+
+
 def test_fill_under_every_occupancy_cap(ec):
     """`ec_fill` reserves unused LDS so that few workgroups per CU write (`write_lds_kb`, 64 KiB by default: two per CU); the knob changes
     the launch, never the cells — every cap, every cell width, ragged lengths, odd window offsets; and the knob reads back."""
