@@ -71,7 +71,8 @@ static void launch_map_u(const Fn& fn, size_t n, hipStream_t s) {
     const size_t stream_bytes[2] = {n * Fn::kIn0, n * Fn::kIn1};
     // ec_fill is a pure write stream with nothing to compute: unused dynamic LDS caps its resident workgroups per CU (the generators
     // load nothing either, but hash every cell — they need their occupancy: 576 -> 879 µs for 2^28 u8 cells under the same cap)
-    const unsigned lds = pure_store<Fn>::value ? static_cast<unsigned>(tuning().write_lds_kb.load()) << 10 : 0u;
+    const unsigned lds = (pure_store<Fn>::value ? static_cast<unsigned>(tuning().write_lds_kb.load())
+                                                : (Fn::kIn0 != 0 ? static_cast<unsigned>(tuning().map_lds_kb.load()) : 0u)) << 10;
     k_map<Fn, U><<<grid_for(tiles), kBlock, lds, s>>>(fn, n, cache_plan(stream_bytes, 2));
 }
 

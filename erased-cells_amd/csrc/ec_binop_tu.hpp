@@ -11,6 +11,9 @@
 
 namespace ecd {
 
+// dynamic LDS bytes of a launch: the knob's value when it is set, else the family's rule (KiB)
+static inline unsigned lds_cap(int knob, int rule_kb) { return static_cast<unsigned>(knob >= 0 ? knob : rule_kb) << 10; }
+
 template <typename L, typename R, int OP>
 static ec_status launch_binop_pair(const void* l, const void* r, size_t n, double* out, hipStream_t s) {
     const Tuning& tu = tuning();
@@ -32,7 +35,7 @@ static ec_status launch_binop_pair(const void* l, const void* r, size_t n, doubl
     const size_t stream_bytes[2] = {n * sizeof(L), l == r ? 0 : n * sizeof(R)};  // l == r: one stream, read twice
     unsigned policy = cache_plan(stream_bytes, 2, n * sizeof(double));
     if (l == r && (policy & 1u)) policy |= 2u;
-    k_binop_direct<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n, head | (policy << 8));
+    k_binop_direct<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, lds_cap(tuning().binop_lds_kb.load(), sizeof(L) == 8 && sizeof(R) == 8 ? 48 : 0), s>>>(lp, rp, out, n, head | (policy << 8));
     return check_launch("binop(direct)");
 }
 
@@ -63,6 +66,7 @@ static ec_status launch_masked_pair(const void* l, const uint8_t* lm, const void
     return check_launch("masked_binop(direct)");
 }
 
+
 template <typename L, int OP>
 static ec_status launch_scalar(const void* l, double rhs, size_t n, double* out, hipStream_t s) {
     const L* lp = static_cast<const L*>(l);
@@ -75,7 +79,7 @@ static ec_status launch_scalar(const void* l, double rhs, size_t n, double* out,
     const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
     const size_t stream_bytes[1] = {n * sizeof(L)};
     const unsigned policy = cache_plan(stream_bytes, 1, n * sizeof(double));
-    k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rhs, out, n, head | (policy << 8));
+    k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, lds_cap(tuning().scalar_lds_kb.load(), sizeof(L) == 8 ? 32 : 0), s>>>(lp, rhs, out, n, head | (policy << 8));
     return check_launch("binop_scalar(direct)");
 }
 

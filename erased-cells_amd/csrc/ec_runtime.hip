@@ -512,6 +512,9 @@ extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     else if (!std::strcmp(key, "inject_pin_refusal")) g_tuning.inject_pin_refusal = value != 0;
     else if (!std::strcmp(key, "expr_fixed")) g_tuning.expr_fixed = value != 0;
     else if (!std::strcmp(key, "write_lds_kb")) g_tuning.write_lds_kb = value < 0 ? 0 : value > 64 ? 64 : static_cast<int>(value);
+    else if (!std::strcmp(key, "binop_lds_kb")) g_tuning.binop_lds_kb = value < 0 ? -1 : value > 64 ? 64 : static_cast<int>(value);
+    else if (!std::strcmp(key, "scalar_lds_kb")) g_tuning.scalar_lds_kb = value < 0 ? -1 : value > 64 ? 64 : static_cast<int>(value);
+    else if (!std::strcmp(key, "map_lds_kb")) g_tuning.map_lds_kb = value < 0 ? 0 : value > 64 ? 64 : static_cast<int>(value);
     else if (!std::strcmp(key, "counts_one_launch")) g_tuning.counts_one_launch = value < 0 ? 0 : value > 2 ? 2 : static_cast<int>(value);
     else if (!std::strcmp(key, "cache_force")) g_tuning.cache_force = value < 0 ? -1 : static_cast<int>(value);
     else if (!std::strcmp(key, "expr_jit")) g_tuning.expr_jit = value < 0 ? 0 : value > 2 ? 2 : static_cast<int>(value);

@@ -56,6 +56,13 @@ struct Tuning {
                                         // per CU (64 KiB: two of 160 KiB).  A write-only stream runs faster from few resident waves — 0.85 of the HBM
                                         // peak at full occupancy, 0.88-0.90 at 2-3 workgroups per CU, 0.93 with write-through stores on top
                                         // (profiles/r04/tune_store_v2.log); any launch that also loads needs its occupancy and gets none.  0 = no cap
+    // Occupancy caps (unused LDS reserved per workgroup) for kernels that load with 16 bytes per lane: such loads keep enough bytes in flight
+    // from fewer waves, and the store stream likes fewer (profiles/r04/write_heavy_caps.md, rotating sets, 16384²): f64 ∘ f64 0.778 -> 0.793 at
+    // 48 KiB (3 workgroups per CU), f64 ∘ scalar 0.806 -> 0.828 at 32 KiB (5).  Every kernel with a NARROW operand loses under any cap
+    // (u8 ∘ scalar 0.75 -> 0.52 at 32 KiB) and takes none.  -1 = that rule; >= 0 forces the reservation for every launch of the family.
+    std::atomic<int> binop_lds_kb{-1};
+    std::atomic<int> scalar_lds_kb{-1};
+    std::atomic<int> map_lds_kb{0};     // experiment knob for the map launches that load (convert, neg, mask_select …): no rule adopted
     std::atomic<int> counts_one_launch{1};  // Mask::counts in ONE launch: every workgroup adds (1 << 40 | its count) to one 64-bit word of the stream's
                                             // scratch with a returning atomic, the workgroup that reads grid - 1 in the upper bits owns the total,
                                             // writes the result and zeroes the word — one device-scope round trip behind the last load instead of a
