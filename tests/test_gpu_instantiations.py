@@ -394,6 +394,34 @@ def test_every_kernel_family_with_every_load_non_temporal(ec, pool):
         L.ec_tune_set(b"mall_mb", 256)
 
 
+def test_every_load_policy_arm_by_force(ec, pool):
+    """`cache_force` pins the launch's load policy to given bits (the A/B hook behind profiles/r04/cache_plan_ab.md): every arm of the
+    two-stream kernels (00, 01, 10, 11) and a spread of the four-stream masked kernel's sixteen computes the oracle's cells — the policy
+    changes instructions' cache modifiers, never results; and the equal-peer rule's answer for the launch shapes it was made for is
+    visible through the hook's absence (results again)."""
+    host, dev, m, dm = pool
+    L = ec.lib()
+    try:
+        for force in (0, 1, 2, 3):
+            L.ec_tune_set(b"cache_force", force)
+            for lt, rt in ((eco.U8, eco.U16), (eco.U8, eco.U8), (eco.I16, eco.F32), (eco.F64, eco.I64)):
+                for op in OPS:
+                    exp = eco.f_binop(op, host[lt][:N], host[rt][:N])
+                    got = dev[lt].shard(0, N)._binop(op, dev[rt].shard(0, N))
+                    assert_f64_bits_equal(got.to_numpy(), exp, nan_by_class_where=_loose(op, host[lt][:N], host[rt][:N]))
+                got = dev[lt].shard(1, N)._binop(eco.MUL, 2.5)
+                assert_f64_bits_equal(got.to_numpy(), eco.f_binop(eco.MUL, host[lt][1:1 + N], np.full(N, 2.5)))
+        for force in (0, 5, 10, 15, 6, 9):
+            L.ec_tune_set(b"cache_force", force)
+            a, b = ec.MaskedCellBuffer(dev[eco.F32].shard(0, N), dm[0].shard(0, N)), ec.MaskedCellBuffer(dev[eco.U8].shard(0, N), dm[1].shard(0, N))
+            got = a._binop(eco.DIV, b)
+            assert_f64_bits_equal(got.buffer().to_numpy(), eco.f_binop(eco.DIV, host[eco.F32][:N], host[eco.U8][:N]),
+                                  nan_by_class_where=_loose(eco.DIV, host[eco.F32][:N], host[eco.U8][:N]))
+            assert np.array_equal(got.mask().to_numpy(), m[0][:N] & m[1][:N])
+    finally:
+        L.ec_tune_set(b"cache_force", -1)
+
+
 # ---------------------------------------------------------------- expression programs (ec_expr): trees of any depth in one pass
 def _oracle_program(streams, scalars, steps):
     """The program evaluated step by step on the oracle's typed loops — the eager chain the reference would run — and the
