@@ -130,11 +130,11 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
 #endif
         } else {
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                D2 o;
-                o.x = cell_op<OP, FP, SM>(to_f64(a[j][0]), to_f64(b[j][0]));
-                o.y = cell_op<OP, FP, SM>(to_f64(a[j][1]), to_f64(b[j][1]));
-                store_vec<NT_ST>(op + base + size_t(j) * kBlock, o);
+            for (int j = 0; j < U; ++j) {  // chunk by chunk, the NaN rule tested once per chunk (cell_op_n, ec_device.hpp)
+                const double av[2] = {to_f64(a[j][0]), to_f64(a[j][1])}, bv[2] = {to_f64(b[j][0]), to_f64(b[j][1])};
+                double o[2];
+                cell_op_n<OP, FP, SM, 2>(av, bv, o);
+                store_vec<NT_ST>(op + base + size_t(j) * kBlock, D2{o[0], o[1]});
             }
         }
     } else {
@@ -144,7 +144,7 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
             if (p < npairs) {
                 const cells<L, 2> a = load_cells<NT_LD, L, 2>(l + 2 * p);
                 const cells<R, 2> b = load_cells<NT_LD, R, 2>(r + 2 * p);
-                D2 o;
+                D2 o;  // the ragged last tile: lanes diverge here anyway (p < npairs), the per-cell form is as good
                 o.x = cell_op<OP, FP, SM>(to_f64(a[0]), to_f64(b[0]));
                 o.y = cell_op<OP, FP, SM>(to_f64(a[1]), to_f64(b[1]));
                 store_vec<NT_ST>(op + p, o);
@@ -180,11 +180,14 @@ __device__ __forceinline__ void binop_direct_body(const L* __restrict__ l, const
         st_cell(cell_op<OP, FP, SM>(to_f64(ld_cell(l + n - 1)), to_f64(ld_cell(r + n - 1))), out + n - 1);
 }
 
-template <typename L, int OP, int U, bool NT_ST, bool NT_LD>
+// NANRULE: cv_bin_op!'s NaN rule is compiled in.  The scalar may be any of the 10 types (widened to f64 on the host), so in general a result
+// can be a NaN; but integer cells with a FINITE scalar (non-zero for a divide) cannot produce one — finite op finite is finite or ±inf — and
+// the host then launches the form without the rule (u8 * 2.0, the reference's own example: 0.774 -> 0.80 with every byte from HBM).
+template <typename L, int OP, int U, bool NT_ST, bool NT_LD, bool NANRULE = true>
 __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, double s, double* __restrict__ out,
                                                   size_t npairs, size_t tile, unsigned cacheable) {
     using D2 = vec<double, 2>;
-    constexpr bool FP = true;  // the scalar may be any of the 10 types, widened to f64 on the host
+    constexpr bool FP = NANRULE;
     constexpr size_t TILE = size_t(kBlock) * U;
     D2* __restrict__ op = reinterpret_cast<D2*>(out);
     const size_t base = tile * TILE + threadIdx.x;
@@ -197,10 +200,10 @@ __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, doubl
         });
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            D2 o;
-            o.x = cell_op<OP, FP>(to_f64(a[j][0]), s);
-            o.y = cell_op<OP, FP>(to_f64(a[j][1]), s);
-            store_vec<NT_ST>(op + base + size_t(j) * kBlock, o);
+            const double av[2] = {to_f64(a[j][0]), to_f64(a[j][1])}, bv[2] = {s, s};
+            double o[2];
+            cell_op_n<OP, FP, false, 2>(av, bv, o);
+            store_vec<NT_ST>(op + base + size_t(j) * kBlock, D2{o[0], o[1]});
         }
     } else {
 #pragma unroll
@@ -217,7 +220,7 @@ __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, doubl
     }
 }
 
-template <typename L, int OP, int U, bool NT_ST, bool NT_LD>
+template <typename L, int OP, int U, bool NT_ST, bool NT_LD, bool NANRULE = true>
 __global__ __launch_bounds__(kBlock) void k_binop_scalar_direct(const L* __restrict__ l, double s,
                                                                 double* __restrict__ out, size_t n, unsigned head_and_policy) {
     const unsigned head = head_and_policy & 0xffu, cacheable = head_and_policy >> 8;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void k_binop_scalar_direct(const L* __restr
         out += head;
         n -= head;
     }
-    binop_scalar_tile<L, OP, U, NT_ST, NT_LD>(l, s, out, n >> 1, two_front_tile(), cacheable);
+    binop_scalar_tile<L, OP, U, NT_ST, NT_LD, NANRULE>(l, s, out, n >> 1, two_front_tile(), cacheable);
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) st_cell(cell_op<OP, true>(to_f64(ld_cell(l + n - 1)), s), out + n - 1);
 }
 
@@ -325,10 +328,10 @@ __device__ __forceinline__ void binop_lds_body(const L* __restrict__ l, const R*
         D2* o2 = reinterpret_cast<D2*>(out + cell0);
 #pragma unroll
         for (int j = 0; j < kLdsChunks; ++j) {
-            D2 o;
-            o.x = cell_op<OP, FP, SM>(to_f64(a[j].x), to_f64(b[j].x));
-            o.y = cell_op<OP, FP, SM>(to_f64(a[j].y), to_f64(b[j].y));
-            store_vec<NT_ST>(o2 + j * kWave + lane, o);
+            const double av[2] = {to_f64(a[j].x), to_f64(a[j].y)}, bv[2] = {to_f64(b[j].x), to_f64(b[j].y)};
+            double o[2];
+            cell_op_n<OP, FP, SM, 2>(av, bv, o);
+            store_vec<NT_ST>(o2 + j * kWave + lane, D2{o[0], o[1]});
         }
     }
     // ragged tail (< one wave tile): cell-wise by workgroup 0

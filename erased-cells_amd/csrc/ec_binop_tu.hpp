@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "ec_binop_kernels.hpp"
 #include "ec_runtime.hpp"
 
@@ -79,7 +81,15 @@ static ec_status launch_scalar(const void* l, double rhs, size_t n, double* out,
     const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
     const size_t stream_bytes[1] = {n * sizeof(L)};
     const unsigned policy = cache_plan(stream_bytes, 1, n * sizeof(double));
-    k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, lds_cap(tuning().scalar_lds_kb.load(), sizeof(L) == 8 ? 32 : 0), s>>>(lp, rhs, out, n, head | (policy << 8));
+    const unsigned lds = lds_cap(tuning().scalar_lds_kb.load(), sizeof(L) == 8 ? 32 : 0);
+    if constexpr (!is_fp<L>::value) {
+        // integer cells and a finite scalar (non-zero for a divide): no result can be a NaN — the form without the NaN rule
+        if (std::isfinite(rhs) && !(OP == EC_DIV && rhs == 0.0)) {
+            k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad, false><<<grid_for(tiles), kBlock, lds, s>>>(lp, rhs, out, n, head | (policy << 8));
+            return check_launch("binop_scalar(direct, no NaN possible)");
+        }
+    }
+    k_binop_scalar_direct<L, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, lds, s>>>(lp, rhs, out, n, head | (policy << 8));
     return check_launch("binop_scalar(direct)");
 }
 

@@ -118,6 +118,33 @@ __device__ __forceinline__ double cell_op(double a, double b) {
     return res;
 }
 
+// cv_bin_op! for the N cells a lane holds for one store (N = 2: a 16-byte output slot), the NaN rule tested ONCE for all of them and
+// handled out of line behind a wave-uniform branch.  cell_op<OP, true> tests every cell with a lane-wise branch (v_cmp_u_f64, s_and_saveexec,
+// s_cbranch_execnz — per cell); in kernels that are bound by how long a workgroup lives those four branches per tile cost 5-12 % (buffer ∘
+// scalar u8: 0.70 with them, 0.79 without, same tile, same loads and stores: profiles/r04/nan_rule_per_pair.md).  Same cells: a NaN result
+// takes the first NaN operand quieted, the x86 default NaN when neither operand is one.
+template <int OP, bool FP_IN, bool SMALL_INT, int N>
+__device__ __forceinline__ void cell_op_n(const double (&a)[N], const double (&b)[N], double (&r)[N]) {
+    if constexpr (!FP_IN) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) r[i] = cell_op<OP, false, SMALL_INT>(a[i], b[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) r[i] = apply_op<OP>(a[i], b[i]);
+        bool nan = false;
+#pragma unroll
+        for (int i = 0; i + 1 < N; i += 2) nan = nan || __builtin_isunordered(r[i], r[i + 1]);
+        if constexpr (N & 1) nan = nan || r[N - 1] != r[N - 1];
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(nan) != 0, 0)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const uint64_t fix = (a[i] != a[i]) ? (f64_bits(a[i]) | kQuietBit) : (b[i] != b[i]) ? (f64_bits(b[i]) | kQuietBit) : kNegQNaN;
+                r[i] = (r[i] != r[i]) ? bits_f64(fix) : r[i];
+            }
+        }
+    }
+}
+
 // f32/f64::total_cmp keys (src/value.rs:260-261) and their integer siblings:
 // every cell type maps to an int64 whose natural order is the reference order.
 template <typename T>

@@ -111,19 +111,11 @@ __device__ __forceinline__ void widen_pairs(const typename raw_pair<C>::type (&r
 // One op over the whole tile's cells: the switch is wave-uniform and OUTSIDE the cell loop.
 template <int N>
 __device__ __forceinline__ void apply_tile(int op, const double (&a)[N], const double (&b)[N], double (&r)[N]) {
-    if (op == EC_ADD) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) r[i] = cell_op<EC_ADD, true>(a[i], b[i]);
-    } else if (op == EC_SUB) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) r[i] = cell_op<EC_SUB, true>(a[i], b[i]);
-    } else if (op == EC_MUL) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) r[i] = cell_op<EC_MUL, true>(a[i], b[i]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) r[i] = cell_op<EC_DIV, true>(a[i], b[i]);
-    }
+    // the NaN rule once for the tile's cells, out of line (cell_op_n, ec_device.hpp) — not a lane-wise branch per cell
+    if (op == EC_ADD) cell_op_n<EC_ADD, true, false, N>(a, b, r);
+    else if (op == EC_SUB) cell_op_n<EC_SUB, true, false, N>(a, b, r);
+    else if (op == EC_MUL) cell_op_n<EC_MUL, true, false, N>(a, b, r);
+    else cell_op_n<EC_DIV, true, false, N>(a, b, r);
 }
 
 __host__ __device__ constexpr int fused_any_min_class(int a, int b, int c, int d) {

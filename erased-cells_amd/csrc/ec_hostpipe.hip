@@ -238,6 +238,7 @@ struct Pipe {
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+constexpr size_t kRegisterFromBytes = size_t(64) << 20;  // link traffic from which a call page-locks the caller's arrays (below: pageable copies)
 
 }  // namespace
 
@@ -296,7 +297,13 @@ static ec_status host_pipeline(const char* what, const ec_dtype* dt, const void*
         for (int k = 0; k < n_streams; ++k) ranges.emplace_back(p_host[k], n * bytes_per_cell[k]);
         ranges.emplace_back(out_host, n * sizeof(double));
         if (out_mask_host) ranges.emplace_back(out_mask_host, n);
-        if (small) pins.use_all(ranges);  // copied by the runtime's pageable path: no registration may come or go under the copies
+        // Page-locking the caller's arrays pays from ≈ 64 MiB over the link — and only such arrays are safe to register: malloc maps them on
+        // their own, so their pages hold nothing else.  SMALL arrays share heap pages with other objects, and the HIP runtime pins heap pages
+        // itself, lazily and with a cache, whenever somebody copies from or to pageable memory (from_vec / to_vec of a neighbour): a
+        // hipHostRegister / hipHostUnregister of the same pages pulls the GPU mapping from under that cache, and a later copy faults on a
+        // HOST address ("Memory access fault by GPU … Reason: Unknown", twice in round 4's suite runs, in a pipeline forced onto 31,434-cell
+        // arrays with chunk_cells = 2000).  Below the threshold the chunks are copied by the runtime's pageable path, whatever chunk_cells says.
+        if (small || link_bytes <= kRegisterFromBytes) pins.use_all(ranges);  // no registration may come or go under the copies
         else pins.pin_all(ranges);
     }
     Pipe pipe;

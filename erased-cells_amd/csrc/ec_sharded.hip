@@ -650,7 +650,12 @@ extern "C" ec_status ec_sharded_host_expr(ec_shard_group* g, const ec_dtype* dt,
         for (int k = 0; k < n_streams; ++k) ranges.emplace_back(p_host[k], n * ecl::size_of(dt[k]));
         ranges.emplace_back(out_host, n * sizeof(double));
         if (out_mask_host_or_null) ranges.emplace_back(out_mask_host_or_null, n);
-        whole.pin_all(ranges);
+        // small rasters are not registered at all (ec_hostpipe.hip: their pages are shared heap pages the runtime pins itself); the shards'
+        // pipelines decide the same way, each for its row-block
+        size_t link = 0;
+        for (const auto& r : ranges) link += r.second;
+        if (link > (size_t(64) << 20)) whole.pin_all(ranges);
+        else whole.use_all(ranges);
     }
     std::lock_guard<std::mutex> lk(g->call_mu);
     return for_each_shard(g, [&](int i) {

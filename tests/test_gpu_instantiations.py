@@ -394,6 +394,26 @@ def test_every_kernel_family_with_every_load_non_temporal(ec, pool):
         L.ec_tune_set(b"mall_mb", 256)
 
 
+def test_scalar_kernels_with_and_without_the_nan_rule(ec, pool):
+    """buffer ∘ scalar runs without cv_bin_op!'s NaN rule when no result can be a NaN — integer cells, a finite scalar, non-zero for a
+    divide — and with it otherwise.  Both forms, every integer and float cell type, scalars on both sides of every condition (0, -0, ±inf,
+    NaN, a finite one, one that overflows the product), against the oracle bit for bit (a NaN scalar against a NaN cell: by class, the
+    reference leaves the winner to the compiler for + and *)."""
+    host, dev, m, dm = pool
+    scalars = [2.5, -3.0, 0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e308, 5e-324]
+    for ct in range(NT):
+        h = host[ct][3:3 + N]
+        d = dev[ct].shard(3, N)
+        for sc in scalars:
+            for op in OPS:
+                exp = eco.f_binop(op, h, np.full(N, sc))
+                got = d._binop(op, sc).to_numpy()
+                try:
+                    assert_f64_bits_equal(got, exp, nan_by_class_where=_loose(op, h, np.full(N, sc)))
+                except AssertionError as e:
+                    raise AssertionError(f"cell type {ct} op {op} scalar {sc!r}: {e}") from None
+
+
 def test_every_load_policy_arm_by_force(ec, pool):
     """`cache_force` pins the launch's load policy to given bits (the A/B hook behind profiles/r04/cache_plan_ab.md): every arm of the
     two-stream kernels (00, 01, 10, 11) and a spread of the four-stream masked kernel's sixteen computes the oracle's cells — the policy

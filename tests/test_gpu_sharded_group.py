@@ -632,7 +632,7 @@ import erased_cells_hip as ec
 from erased_cells_hip import sharded
 refuse, tmp = sys.argv[2] == "1", sys.argv[3]
 ec.init(0)
-rows, cols = 384, 1000
+rows, cols = 3000, 4001  # 12 M cells: 132 MB over the link — above the 64 MiB from which the pipelines page-lock at all
 n = rows * cols
 rng = np.random.default_rng(7)
 a = rng.integers(1, 60000, n, dtype=np.uint16)
@@ -647,13 +647,13 @@ af, bf = a.astype(np.float64), b.astype(np.float64)
 exp = (af - bf) / (af + bf)
 L = ec.lib()
 ec._ffi.check(L.ec_tune_set(b"inject_pin_refusal", 1 if refuse else 0))
-one = ec.fused.program_host([ra, rb], [], prog, chunk_cells=50_000)
+one = ec.fused.program_host([ra, rb], [], prog, chunk_cells=1_000_000)
 assert np.array_equal(one.view(np.uint64), exp.view(np.uint64))
 for G in (1, 3):
     with sharded.ShardGroup([0] * G, host_combine=G > 1) as g:
-        out = g.program_host([ra, rb], [], prog, rows, cols, chunk_cells=50_000)
+        out = g.program_host([ra, rb], [], prog, rows, cols, chunk_cells=1_000_000)
         assert np.array_equal(out.view(np.uint64), exp.view(np.uint64)), G
-        out, valid = g.program_host([ra, rb], [], prog, rows, cols, nodata=[None, 0], out_nodata=-1.0, want_mask=True, chunk_cells=50_000)
+        out, valid = g.program_host([ra, rb], [], prog, rows, cols, nodata=[None, 0], out_nodata=-1.0, want_mask=True, chunk_cells=1_000_000)
         assert np.array_equal(valid, b != 0) and np.array_equal(out[valid].view(np.uint64), exp[valid].view(np.uint64))
         assert np.all(out[~valid] == -1.0)
         # chunk_cells = 0 takes the one-chunk form below 64 MiB: it enters its ranges with use_all and must pass a refused entry of its caller too
@@ -668,7 +668,7 @@ for G in (1, 3):
         st = (ec._ffi.EcExprStep * len(prog))(*[ec._ffi.EcExprStep(*q) for q in prog])
         o = np.empty(n)
         try:
-            ec._ffi.check(L.ec_sharded_host_expr(g.handle, dt, p, nd, k, None, 0, st, len(prog), rows, cols, o.ctypes.data, None, None, 50_000))
+            ec._ffi.check(L.ec_sharded_host_expr(g.handle, dt, p, nd, k, None, 0, st, len(prog), rows, cols, o.ctypes.data, None, None, 1_000_000))
             raise SystemExit("a nodata value of the wrong cell type was accepted")
         except ec._ffi.EcError as e:
             assert "nodata" in str(e), str(e)

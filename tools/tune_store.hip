@@ -157,6 +157,67 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_wide(const uint8_t* __restri
     }
 }
 
+// Workgroup-wide loads: ONE wave-instruction fetches a whole KiB of a narrow operand for the workgroup (lane-contiguous 16 B per lane), the
+// cells reach the four waves through LDS behind a workgroup barrier.  The direct form reads the same KiB as eight 128-byte requests from four
+// waves; the question is whether the DRAM interface likes a write stream interrupted by a few long reads better than by many short ones.
+// SCALAR: out = f64(u8) * 2 (1 B read + 8 B written per cell, the library's worst common kernel: 0.75); else the u8 + u16 mix.
+template <int POL, bool SCALAR, bool WIDE>
+__global__ __launch_bounds__(256) void k_wgwide(const uint8_t* __restrict__ l, const uint16_t* __restrict__ r, D2* __restrict__ op, size_t tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char sa[1024];
+    __shared__ __attribute__((aligned(16))) unsigned char sb[2048];
+    const size_t b = blockIdx.x, tile = (b & 1) ? tiles - 1 - (b >> 1) : (b >> 1);
+    const size_t cell0 = tile * 1024;  // 1024 cells per workgroup: 4 waves x 2 chunks of 128 cells
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t a2[2];
+    uint32_t b2[2] = {0, 0};
+    if constexpr (WIDE) {
+        if (wave == 0) reinterpret_cast<u32x4*>(sa)[lane] = nt_load(reinterpret_cast<const u32x4*>(l + cell0) + lane);
+        if constexpr (!SCALAR) {
+            if (wave == 1) reinterpret_cast<u32x4*>(sb)[lane] = nt_load(reinterpret_cast<const u32x4*>(r + cell0) + lane);
+            if (wave == 2) reinterpret_cast<u32x4*>(sb)[64 + lane] = nt_load(reinterpret_cast<const u32x4*>(r + cell0) + 64 + lane);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pr = j * 256 + threadIdx.x;  // pair index inside the tile, the library's workgroup-interleaved layout
+            a2[j] = reinterpret_cast<const uint16_t*>(sa)[pr];
+            if constexpr (!SCALAR) b2[j] = reinterpret_cast<const uint32_t*>(sb)[pr];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const size_t pr = cell0 / 2 + j * 256 + threadIdx.x;
+            a2[j] = nt_load(reinterpret_cast<const uint16_t*>(l) + pr);
+            if constexpr (!SCALAR) b2[j] = nt_load(reinterpret_cast<const uint32_t*>(r) + pr);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const size_t pr = cell0 / 2 + j * 256 + threadIdx.x;
+        D2 o;
+        if constexpr (SCALAR) o = D2{double(a2[j] & 0xffu) * 2.0, double(a2[j] >> 8) * 2.0};
+        else o = D2{double(a2[j] & 0xffu) + double(b2[j] & 0xffffu), double(a2[j] >> 8) + double(b2[j] >> 16)};
+        store16<POL>(op + pr, o);
+    }
+}
+
+// the library's buffer ∘ scalar tile (k_binop_scalar_direct, full tiles only) with the NaN rule of cv_bin_op! switchable
+template <bool NANRULE>
+__global__ __launch_bounds__(256) void k_scalar_lib_shape(const uint8_t* __restrict__ l, double sc, double* __restrict__ out, size_t n) {
+    D2* __restrict__ op = reinterpret_cast<D2*>(out);
+    const size_t base = two_front_tile() * 512 + threadIdx.x;
+    cells<uint8_t, 2> a[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a[j] = load_cells<true, uint8_t, 2>(l + 2 * (base + size_t(j) * 256));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        D2 o;
+        o.x = cell_op<EC_MUL, NANRULE>(to_f64(a[j][0]), sc);
+        o.y = cell_op<EC_MUL, NANRULE>(to_f64(a[j][1]), sc);
+        nt_store(o, op + base + size_t(j) * 256);
+    }
+}
+
 // Where a wave's life goes: the shipped mix tile with four timestamps per wave (s_memrealtime, 100 MHz) — start, operands back (first use),
 // stores issued, stores acknowledged (s_waitcnt vmcnt(0)) — written for one wave in 64.  The kernel is bound by how long a workgroup lives
 // (its occupancy is the hardware's maximum): this says which part of that life is load latency and which is the wait for the stores.
@@ -451,6 +512,14 @@ int main(int argc, char** argv) {
             k_store<U, WAVES, false, POL, 1, 1, LDSKB, MIX, true, true><<<unsigned(tiles), WAVES * 64>>>(a[i % SETS], b[i % SETS], (D2*)out[i & 1], tiles); \
         });                                                                                                                            \
     }
+#define WG(POL, SCALAR, WIDE)                                                                                                          \
+    {                                                                                                                                  \
+        char nm[160];                                                                                                                  \
+        snprintf(nm, sizeof nm, "%s U2 x4w %s %s 2fronts", SCALAR ? "sca" : "mix", WIDE ? "workgroup-wide loads + LDS" : "direct narrow loads", polname[POL]); \
+        const size_t tiles = n / 1024;                                                                                                 \
+        vs.push_back(Variant{nm, [=](int i) { k_wgwide<POL, SCALAR, WIDE><<<unsigned(tiles), 256>>>(a[i % SETS], b[i % SETS], (D2*)out[i & 1], tiles); }, \
+                             (SCALAR ? 9.0 : 11.0) * double(n), !SCALAR, {}});                                                         \
+    }
 #define SWEEP3                          \
     STW(2, 4, 4, 0, true)               \
     STW(2, 4, 1, 0, true)               \
@@ -488,6 +557,16 @@ int main(int argc, char** argv) {
 #if EC_STORE_SWEEP == 1
     SWEEP1(false)
     SWEEP1(true)
+#elif EC_STORE_SWEEP == 4
+    WG(4, false, false) WG(4, false, true) WG(1, false, true) WG(4, true, false) WG(4, true, true) WG(1, true, false) WG(1, true, true)
+    vs.push_back(Variant{"sca LIB k_binop_scalar_direct<u8, Mul, 2> (the library's kernel, its own stores), all loads nt",
+                         [=](int i) { k_binop_scalar_direct<uint8_t, EC_MUL, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a[i % SETS], 2.0, out[i & 1], n, 0u); }, 9.0 * double(n), false, {}});
+    vs.push_back(Variant{"sca LIB k_binop_scalar_direct<u8, Mul, 2>, operand cacheable (policy bit 0)",
+                         [=](int i) { k_binop_scalar_direct<uint8_t, EC_MUL, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a[i % SETS], 2.0, out[i & 1], n, 1u << 8); }, 9.0 * double(n), false, {}});
+    vs.push_back(Variant{"sca library-shaped tile, NaN rule per cell (cell_op<Mul, true>)", [=](int i) { k_scalar_lib_shape<true><<<unsigned(n / 1024), 256>>>(a[i % SETS], 2.0, out[i & 1], n); }, 9.0 * double(n), false, {}});
+    vs.push_back(Variant{"sca library-shaped tile, no NaN rule (cell_op<Mul, false>)", [=](int i) { k_scalar_lib_shape<false><<<unsigned(n / 1024), 256>>>(a[i % SETS], 2.0, out[i & 1], n); }, 9.0 * double(n), false, {}});
+    vs.push_back(Variant{"mix LIB k_binop_direct<u8, u16, Add, 2> (the library's kernel), all loads nt",
+                         [=](int i) { k_binop_direct<uint8_t, uint16_t, EC_ADD, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a[i % SETS], b[i % SETS], out[i & 1], n, 0u); }, 11.0 * double(n), false, {}});
 #elif EC_STORE_SWEEP == 3
     SWEEP3
 #else
@@ -602,7 +681,7 @@ int main(int argc, char** argv) {
     // checksums: all pure writes must agree with each other, all mixes with each other
     unsigned long long ref_wr = 0, ref_mix = 0;
     for (size_t vi = 0; vi < vs.size(); ++vi)
-        if (vs[vi].name.rfind("ref", 0) != 0 && vs[vi].name.rfind("rd1", 0) != 0) (vs[vi].mix ? ref_mix : ref_wr) = sums[vi];
+        if (vs[vi].name.rfind("ref", 0) != 0 && vs[vi].name.rfind("rd1", 0) != 0 && vs[vi].name.rfind("sca", 0) != 0) (vs[vi].mix ? ref_mix : ref_wr) = sums[vi];
     printf("%-74s %9s %9s %9s %9s %8s  %s\n", "variant", "med_ms", "min_ms", "max_ms", "GB/s", "of8TB/s", "cells");
     int bad = 0;
     for (size_t vi = 0; vi < vs.size(); ++vi) {
@@ -610,7 +689,7 @@ int main(int argc, char** argv) {
         std::sort(v.ms.begin(), v.ms.end());
         const float med = v.ms[v.ms.size() / 2];
         const double gbs = v.bytes / (med * 1e-3) / 1e9;
-        const bool is_ref = v.name.rfind("ref", 0) == 0 || v.name.rfind("rd1", 0) == 0;
+        const bool is_ref = v.name.rfind("ref", 0) == 0 || v.name.rfind("rd1", 0) == 0 || v.name.rfind("sca", 0) == 0;
         const bool ok = is_ref || sums[vi] == (v.mix ? ref_mix : ref_wr);
         bad += !ok;
         printf("%-74s %9.4f %9.4f %9.4f %9.1f %8.4f  %s\n", v.name.c_str(), med, v.ms[0], v.ms.back(), gbs, gbs / 8000.0,
