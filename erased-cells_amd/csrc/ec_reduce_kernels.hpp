@@ -381,8 +381,17 @@ __global__ __launch_bounds__(kRBlock) void k_first_diff_partials(const W* __rest
                         b[j] = load_cells<!(B & 2u), W, CPL>(r + (base + size_t(j) * kRBlock) * CPL);
                     }
                 });
+                // equal tiles (the common case, and all of a scan that ends in "equal") leave through ONE wave-uniform branch: the
+                // tile's 2 U groups are xor-ed and or-ed together first and the wave votes; only a wave that holds a difference
+                // looks at its groups one by one (before round 4: a lane-wise branch per group, eight per tile, in a kernel bound by
+                // how long a workgroup lives — the NaN rule's lesson, profiles/r04/nan_rule_per_pair.md)
+                u32x4 any = {0, 0, 0, 0};
 #pragma unroll
-                for (int j = 0; j < U; ++j) compare(base + size_t(j) * kRBlock, a[j], b[j]);
+                for (int j = 0; j < U; ++j) any |= __builtin_bit_cast(u32x4, a[j].v) ^ __builtin_bit_cast(u32x4, b[j].v);
+                if (__builtin_amdgcn_ballot_w64((any.x | any.y | any.z | any.w) != 0) != 0) {
+#pragma unroll
+                    for (int j = 0; j < U; ++j) compare(base + size_t(j) * kRBlock, a[j], b[j]);
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < U; ++j) {
