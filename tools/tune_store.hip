@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -267,6 +268,111 @@ __global__ __launch_bounds__(WAVES * 64) void k_store_persistent(const uint8_t* 
         const size_t per = tiles >> 3, lo = (b & 7) * per, gx = g >> 3;
         for (size_t t = b >> 3; t < per; t += gx) store_tile<U, WAVES, WC, POL, MIX>(l, r, op, lo + t);
     }
+}
+
+// Fifth sweep: PERSISTENT workgroups with the operand loads SOFTWARE-PIPELINED.  The one-tile-per-workgroup kernel is bound by how long a
+// workgroup lives (wave-life: 1.4 us waiting for operands, 1.0 us waiting for the store acknowledgement, no load in flight during the
+// latter); the persistent variants of sweeps 1-2 walked their tiles one after the other (load, wait, store, load ...) and lost.  Here a
+// wave keeps D tiles of operands in flight: stage s is computed and stored, then reloaded with the tile D steps ahead, while the other
+// D - 1 stages' loads are still outstanding.  The stores are buffer stores through the compiler's own builtin (aux = sc1 | nt), so the
+// compiler's s_waitcnt insertion sees them and waits with vmcnt(N > 0) — behind inline-asm stores it cannot count them and waits for
+// the store acknowledgement too.  ASSIGN 0: tile = b + k * grid   1: the same through the two-fronts map   2: next tile from an atomic
+// counter (one fetch-add per workgroup and tile, broadcast through LDS): the window of tiles in work stays as tight as the dispatcher
+// keeps it for one-tile workgroups, whatever the drift between workgroups.
+__global__ void k_set(unsigned* p, unsigned v) { *p = v; }
+template <class F, int... S>
+__device__ __forceinline__ bool any_stage(F& f, std::integer_sequence<int, S...>) {
+    return (f(std::integral_constant<int, S>{}) || ...);
+}
+// ASSIGN 0: stage s of step k works on tile b + (k D + s) grid   1: the same through the two-fronts map
+//        3: CHUNKS of D adjacent tiles: step k works on chunk b + k grid, stage s on its s-th tile
+//        2: chunks from an atomic counter, one fetch-add per workgroup and chunk, issued inside stage 0 BEFORE that stage's loads and taken
+//           one step later behind the wait for those loads (vmcnt counts in order: it has returned by then, at no extra wait).
+// Everything that touches memory is inline asm with hand-placed s_waitcnt: the compiler, left to itself, sank the prefetches to their
+// uses (restrict + const: no memory clobber holds them), hoisted the next stage's arithmetic above them, and merged the waits of the
+// prologue and the loop into vmcnt(3) (three builds' ISA, all without a pipeline).  The loaded registers reach their uses only through
+// the "+v" operands of the asm statement behind the wait.
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int U, int D, int ASSIGN>
+__global__ __launch_bounds__(256) void k_mix_pipe(const uint8_t* __restrict__ l, const uint16_t* __restrict__ r, D2* __restrict__ op, size_t tiles,
+                                                  unsigned* __restrict__ counter) {
+    const size_t g = gridDim.x;
+    constexpr bool CHUNKS = ASSIGN >= 2;
+    static_assert((D - 1) * 3 * U + 1 <= 63, "vmcnt is a 6-bit counter");
+    static_assert(D * U <= 8, "more stages: the stage arrays go to scratch and the asm loads' results are copied there before they have arrived (tools/inflight_check.py)");
+    __shared__ unsigned handoff[2];
+    uint32_t a[D][U], c[D][U];
+    size_t cur = blockIdx.x, nxt = CHUNKS ? blockIdx.x + g : blockIdx.x + D * g;  // chunk (or step) of the tiles being stored / being loaded
+    unsigned step = 0, fut = 0;
+    const unsigned one = 1;
+    auto tile_of = [&](size_t q, int s) -> size_t {
+        if constexpr (CHUNKS) return q * D + s;
+        else return q + s * g;  // q = b + k D g
+    };
+    auto where = [&](size_t v) -> size_t {
+        if constexpr (ASSIGN == 1) return (v & 1) ? tiles - 1 - (v >> 1) : (v >> 1);
+        else return v;
+    };
+    auto load = [&](int s, size_t q) {  // unconditional: past the end the last tile again, unused
+        const size_t t = tile_of(q, s);
+        const size_t base = where(t < tiles ? t : tiles - 1) * (256 * U) + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            asm volatile("global_load_ushort %0, %1, off nt" : "=v"(a[s][j]) : "v"(reinterpret_cast<const uint16_t*>(l) + base + j * 256) : "memory");
+            asm volatile("global_load_dword %0, %1, off nt" : "=v"(c[s][j]) : "v"(reinterpret_cast<const uint32_t*>(r) + base + j * 256) : "memory");
+        }
+    };
+    auto fetch = [&]() {
+        if (threadIdx.x == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(fut) : "v"(counter), "v"(one) : "memory");
+    };
+    if constexpr (ASSIGN == 2) {  // the counter starts at grid: chunk b is this workgroup's first, the next comes from the queue
+        fetch();
+        wait_vm<0>();
+        asm volatile("" : "+v"(fut));
+        if (threadIdx.x == 0) handoff[1] = fut;
+        __syncthreads();
+        nxt = handoff[1];
+        fetch();  // for step 1, taken in step 0's stage 0... no: taken in step 1's stage 0
+    }
+#pragma unroll
+    for (int s = 0; s < D; ++s) load(s, cur);
+    // FIRST: the pass over the prologue's loads — behind the loads of stage s there are the loads of the later stages (2 U each) and what the
+    // earlier stages of this pass issued (U stores + 2 U loads each); afterwards always the other D - 1 stages' stores and loads.
+    auto stage = [&](auto S, auto First) -> bool {  // true: this workgroup has run out of tiles
+        constexpr int s = decltype(S)::value;
+        constexpr bool FIRST = decltype(First)::value;
+        const size_t t = tile_of(cur, s);
+        if (t >= tiles) return true;
+        wait_vm<FIRST ? (D - 1 - s) * 2 * U + s * 3 * U : (D - 1) * 3 * U>();
+#pragma unroll
+        for (int j = 0; j < U; ++j) asm volatile("" : "+v"(a[s][j]), "+v"(c[s][j]));
+        if constexpr (ASSIGN == 2 && s == 0 && !FIRST) {
+            asm volatile("" : "+v"(fut));
+            if (threadIdx.x == 0) handoff[step & 1] = fut;
+            fetch();
+            __syncthreads();
+            nxt = handoff[step & 1];
+        }
+        const size_t base = where(t) * (256 * U) + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+            store16<4>(op + base + j * 256, D2{double(a[s][j] & 0xffu) + double(c[s][j] & 0xffffu), double((a[s][j] >> 8) & 0xffu) + double(c[s][j] >> 16)});
+        load(s, nxt);
+        return false;
+    };
+    auto pass = [&](auto First) -> bool {
+        return [&]<int... S>(std::integer_sequence<int, S...>) { return (stage(std::integral_constant<int, S>{}, First) || ...); }
+        (std::make_integer_sequence<int, D>{});
+    };
+    bool done = pass(std::true_type{});
+    while (!done) {
+        cur = nxt;
+        ++step;
+        if constexpr (ASSIGN != 2) nxt += CHUNKS ? g : D * g;
+        done = pass(std::false_type{});
+    }
+    wait_vm<0>();
 }
 
 __global__ void k_fill(uint8_t* a, uint16_t* b, size_t n, uint64_t seed) {
@@ -567,6 +673,29 @@ int main(int argc, char** argv) {
     vs.push_back(Variant{"sca library-shaped tile, no NaN rule (cell_op<Mul, false>)", [=](int i) { k_scalar_lib_shape<false><<<unsigned(n / 1024), 256>>>(a[i % SETS], 2.0, out[i & 1], n); }, 9.0 * double(n), false, {}});
     vs.push_back(Variant{"mix LIB k_binop_direct<u8, u16, Add, 2> (the library's kernel), all loads nt",
                          [=](int i) { k_binop_direct<uint8_t, uint16_t, EC_ADD, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a[i % SETS], b[i % SETS], out[i & 1], n, 0u); }, 11.0 * double(n), false, {}});
+#elif EC_STORE_SWEEP == 5
+    ST(2, 4, false, 4, 1, 1, 0, true)
+    ST(2, 4, false, 1, 1, 1, 0, true)
+    unsigned* tile_counter;
+    CK(hipMalloc(&tile_counter, 4));
+#define PP(U, D, ASSIGN, BPC)                                                                                                          \
+    if (npairs % (size_t(256) * U) == 0 && npairs * 16 <= 0xffffffffull) {                                                             \
+        char nm[160];                                                                                                                  \
+        snprintf(nm, sizeof nm, "mix U%d x4w pipelined persistent D%d %s %d/CU %s", U, D,                                              \
+                 ASSIGN == 0 ? "grid-stride" : ASSIGN == 1 ? "grid-stride-2fronts" : ASSIGN == 2 ? "chunks-atomic-queue" : "chunks-grid-stride", BPC, "nt+sc1");                                      \
+        const size_t tiles = npairs / (size_t(256) * U);                                                                               \
+        add(nm, true, [=](int i) {                                                                                                     \
+            if (ASSIGN == 2) k_set<<<1, 1>>>(tile_counter, unsigned(cus * BPC));                                                                \
+            k_mix_pipe<U, D, ASSIGN><<<unsigned(cus * BPC), 256>>>(a[i % SETS], b[i % SETS], (D2*)out[i & 1], tiles, tile_counter); \
+        });                                                                                                                            \
+    }
+    PP(2, 2, 0, 8) PP(2, 2, 1, 8) PP(2, 2, 2, 8) PP(2, 2, 3, 8)
+    PP(2, 2, 0, 4) PP(2, 2, 2, 4) PP(2, 2, 0, 2) PP(2, 2, 2, 2)
+    PP(2, 3, 0, 8) PP(2, 3, 2, 8) PP(2, 3, 0, 4) PP(2, 3, 2, 4) PP(2, 3, 2, 2)
+    PP(2, 4, 0, 8) PP(2, 4, 2, 8) PP(2, 4, 3, 8) PP(2, 4, 0, 4) PP(2, 4, 2, 4) PP(2, 4, 3, 4) PP(2, 4, 2, 2)
+    PP(1, 2, 0, 8) PP(1, 4, 0, 8) PP(1, 4, 2, 8) PP(1, 4, 2, 4)
+    PP(4, 2, 0, 8) PP(4, 2, 2, 4) PP(4, 2, 2, 2)
+    PP(2, 1, 0, 8)
 #elif EC_STORE_SWEEP == 3
     SWEEP3
 #else
@@ -660,12 +789,14 @@ int main(int argc, char** argv) {
         for (size_t oi = 0; oi < order.size(); ++oi) {
             Variant& v = vs[order[oi]];
             if (round < 0) {  // correctness pass: every variant must write every cell (operand set 0, output 0)
+                fprintf(stderr, "check %s\n", v.name.c_str());
                 CK(hipMemset(out[0], 0xEE, n * 8));
                 v.launch(0);
                 CK(hipGetLastError());
                 CK(hipMemset(acc, 0, 8));
                 k_checksum<<<2048, 256>>>((const uint64_t*)out[0], n, acc);
                 CK(hipMemcpy(&sums[order[oi]], acc, 8, hipMemcpyDeviceToHost));
+                CK(hipDeviceSynchronize());
                 continue;
             }
             for (int i = 0; i < 2; ++i) v.launch(launch_no++);
