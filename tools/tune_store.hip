@@ -454,7 +454,15 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&b[k], n * 2));
         k_fill<<<2048, 256>>>(a[k], b[k], n, 0x5EED0000 + 16 * k);
     }
-    for (int k = 0; k < 2; ++k) CK(hipMalloc(&out[k], n * 8));
+    // argv[5]: how the OUTPUT is allocated — "uncached" (hipDeviceMallocUncached: MTYPE UC, stores and loads bypass the L2s) or
+    // "finegrained" (hipDeviceMallocFinegrained) instead of plain hipMalloc: the library hands out its buffers itself (ec_alloc)
+    const char* out_alloc = argc > 5 ? argv[5] : "default";
+    for (int k = 0; k < 2; ++k) {
+        if (!strcmp(out_alloc, "uncached")) CK(hipExtMallocWithFlags((void**)&out[k], n * 8, hipDeviceMallocUncached));
+        else if (!strcmp(out_alloc, "finegrained")) CK(hipExtMallocWithFlags((void**)&out[k], n * 8, hipDeviceMallocFinegrained));
+        else CK(hipMalloc(&out[k], n * 8));
+    }
+    printf("output allocation: %s\n", out_alloc);
     CK(hipMalloc(&acc, 8));
     CK(hipMalloc(&sink, 4));
     CK(hipDeviceSynchronize());
@@ -696,6 +704,19 @@ int main(int argc, char** argv) {
     PP(1, 2, 0, 8) PP(1, 4, 0, 8) PP(1, 4, 2, 8) PP(1, 4, 2, 4)
     PP(4, 2, 0, 8) PP(4, 2, 2, 4) PP(4, 2, 2, 2)
     PP(2, 1, 0, 8)
+#elif EC_STORE_SWEEP == 6
+    ST(2, 4, false, 4, 1, 1, 0, true)
+    ST(2, 4, false, 1, 1, 1, 0, true)
+    ST(2, 4, false, 0, 1, 1, 0, true)
+    ST(2, 4, false, 2, 1, 1, 0, true)
+    ST(2, 4, false, 4, 1, 1, 24, true)
+    ST(4, 4, false, 4, 1, 1, 0, true)
+    ST(2, 4, false, 4, 1, 1, 0, false)
+    ST(2, 4, false, 1, 1, 1, 0, false)
+    ST(2, 4, false, 0, 1, 1, 0, false)
+    ST(2, 4, false, 4, 1, 1, 64, false)
+    ST(2, 4, false, 1, 1, 1, 64, false)
+    ST(2, 4, false, 0, 1, 1, 64, false)
 #elif EC_STORE_SWEEP == 3
     SWEEP3
 #else
