@@ -54,6 +54,19 @@ __device__ __forceinline__ size_t two_front_tile() {
     return (b & 1) ? size_t(gridDim.x) - 1 - (b >> 1) : (b >> 1);
 }
 
+// Where a lane's pairs sit inside its workgroup's tile of kBlock * U pairs.  EC_WAVE_CONTIG = 0: chunk j of all four waves is one
+// contiguous run (lane = threadIdx.x, stride kBlock); 1: each wave owns U contiguous chunks (its 64 U pairs: 2 U KiB of f64 output,
+// its operand loads of the U chunks adjacent) — tools/tune_store.hip "wave-contig", +0.6 % on the 3 B-read / 8 B-write mix.
+#ifndef EC_WAVE_CONTIG
+#define EC_WAVE_CONTIG 0
+#endif
+constexpr size_t tile_stride() { return EC_WAVE_CONTIG ? size_t(kWave) : size_t(kBlock); }
+template <int U>
+__device__ __forceinline__ size_t tile_lane_offset() {
+    if constexpr (EC_WAVE_CONTIG) return size_t(threadIdx.x / kWave) * (size_t(kWave) * U) + (threadIdx.x & (kWave - 1));
+    else return threadIdx.x;
+}
+
 // ---------------------------------------------------------------------------
 // DIRECT variant: one block tile of kBlock*U pairs (2 cells each).  Pointers may sit
 // at any cell offset (under-aligned accesses, ec_device.hpp); the cell-wise kernels run
@@ -67,7 +80,8 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
     constexpr bool SM = is_small_int<L>::value && is_small_int<R>::value;  // 6-instruction exact divide (ec_device.hpp)
     constexpr size_t TILE = size_t(kBlock) * U;
     D2* __restrict__ op = reinterpret_cast<D2*>(out);
-    const size_t base = tile * TILE + threadIdx.x;
+    constexpr size_t kStride = tile_stride();
+    const size_t base = tile * TILE + tile_lane_offset<U>();
     if (tile * TILE + TILE <= npairs) {
         cells<L, 2> a[U];  // 1-byte operands travel as 16-bit words so that their loads keep `nt` (ec_device.hpp)
         cells<R, 2> b[U];
@@ -75,8 +89,8 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
             constexpr unsigned B = decltype(bits)::value;
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                a[j] = load_cells<NT_LD && !(B & 1u), L, 2>(l + 2 * (base + size_t(j) * kBlock));
-                b[j] = load_cells<NT_LD && !(B & 2u), R, 2>(r + 2 * (base + size_t(j) * kBlock));
+                a[j] = load_cells<NT_LD && !(B & 1u), L, 2>(l + 2 * (base + size_t(j) * kStride));
+                b[j] = load_cells<NT_LD && !(B & 2u), R, 2>(r + 2 * (base + size_t(j) * kStride));
             }
         });
         if constexpr (OP == EC_DIV && SM && !FP) {
@@ -107,7 +121,7 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
 #pragma unroll
                     for (int i = 0; i < 2; ++i) q[i] = bv[i] == 0.0 ? div_by_zero(av[i]) : q[i];
                 }
-                store_vec<NT_ST>(op + base + size_t(j) * kBlock, D2{q[0], q[1]});
+                store_vec<NT_ST>(op + base + size_t(j) * kStride, D2{q[0], q[1]});
             }
 #else
             double av[2 * U], bv[2 * U], q[2 * U], y[2 * U], e[2 * U];
@@ -126,7 +140,7 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
                 for (int i = 0; i < 2 * U; ++i) q[i] = bv[i] == 0.0 ? div_by_zero(av[i]) : q[i];
             }
 #pragma unroll
-            for (int j = 0; j < U; ++j) store_vec<NT_ST>(op + base + size_t(j) * kBlock, D2{q[2 * j], q[2 * j + 1]});
+            for (int j = 0; j < U; ++j) store_vec<NT_ST>(op + base + size_t(j) * kStride, D2{q[2 * j], q[2 * j + 1]});
 #endif
         } else {
 #pragma unroll
@@ -134,13 +148,13 @@ __device__ __forceinline__ void binop_direct_tile(const L* __restrict__ l, const
                 const double av[2] = {to_f64(a[j][0]), to_f64(a[j][1])}, bv[2] = {to_f64(b[j][0]), to_f64(b[j][1])};
                 double o[2];
                 cell_op_n<OP, FP, SM, 2>(av, bv, o);
-                store_vec<NT_ST>(op + base + size_t(j) * kBlock, D2{o[0], o[1]});
+                store_vec<NT_ST>(op + base + size_t(j) * kStride, D2{o[0], o[1]});
             }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const size_t p = base + size_t(j) * kBlock;
+            const size_t p = base + size_t(j) * kStride;
             if (p < npairs) {
                 const cells<L, 2> a = load_cells<NT_LD, L, 2>(l + 2 * p);
                 const cells<R, 2> b = load_cells<NT_LD, R, 2>(r + 2 * p);
@@ -190,25 +204,26 @@ __device__ __forceinline__ void binop_scalar_tile(const L* __restrict__ l, doubl
     constexpr bool FP = NANRULE;
     constexpr size_t TILE = size_t(kBlock) * U;
     D2* __restrict__ op = reinterpret_cast<D2*>(out);
-    const size_t base = tile * TILE + threadIdx.x;
+    constexpr size_t kStride = tile_stride();
+    const size_t base = tile * TILE + tile_lane_offset<U>();
     if (tile * TILE + TILE <= npairs) {
         cells<L, 2> a[U];
         policy_arms<1>(cacheable, [&](auto bits) {
             constexpr unsigned B = decltype(bits)::value;
 #pragma unroll
-            for (int j = 0; j < U; ++j) a[j] = load_cells<NT_LD && !(B & 1u), L, 2>(l + 2 * (base + size_t(j) * kBlock));
+            for (int j = 0; j < U; ++j) a[j] = load_cells<NT_LD && !(B & 1u), L, 2>(l + 2 * (base + size_t(j) * kStride));
         });
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const double av[2] = {to_f64(a[j][0]), to_f64(a[j][1])}, bv[2] = {s, s};
             double o[2];
             cell_op_n<OP, FP, false, 2>(av, bv, o);
-            store_vec<NT_ST>(op + base + size_t(j) * kBlock, D2{o[0], o[1]});
+            store_vec<NT_ST>(op + base + size_t(j) * kStride, D2{o[0], o[1]});
         }
     } else {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const size_t p = base + size_t(j) * kBlock;
+            const size_t p = base + size_t(j) * kStride;
             if (p < npairs) {
                 const cells<L, 2> a = load_cells<NT_LD, L, 2>(l + 2 * p);
                 D2 o;
