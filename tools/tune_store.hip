@@ -158,6 +158,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_mix_wide(const uint8_t* __restri
     }
 }
 
+// Seventh sweep: buffer * scalar over 1-byte cells (1 B read + 8 B written per cell: the library's most write-heavy common kernel, 0.79)
+// with WIDE loads under occupancy caps.  A wave fetches its 128 U cells with one load of 2 U bytes per lane (U = 2: dword, 4: dwordx2,
+// 8: dwordx4), parks them in a wave-private LDS slab and reads back the pair of cells of each 16-byte output slot: the operand bytes in
+// flight come from 1/U of the load instructions, so the kernel may tolerate the few resident workgroups the store stream likes (fill: 0.95).
+template <int U, int WAVES, int POL, int LDSKB>
+__global__ __launch_bounds__(WAVES * 64) void k_sca_wide(const uint8_t* __restrict__ l, D2* __restrict__ op, size_t tiles) {
+    reserve_lds<LDSKB>();
+    using LA = vec<uint32_t, U / 2>;  // 2 U bytes per lane
+    __shared__ __attribute__((aligned(16))) unsigned char slab[WAVES][128 * U];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t b = blockIdx.x, tile = (b & 1) ? tiles - 1 - (b >> 1) : (b >> 1);
+    const size_t cell0 = (tile * WAVES + wave) * (128 * U);
+    const LA av = nt_load(reinterpret_cast<const LA*>(l + cell0) + lane);
+    reinterpret_cast<LA*>(slab[wave])[lane] = av;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    D2* o2 = op + cell0 / 2;
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const uint16_t a2 = reinterpret_cast<const uint16_t*>(slab[wave])[j * 64 + lane];
+        store16<POL>(o2 + j * 64 + lane, D2{double(a2 & 0xffu) * 2.0, double(a2 >> 8) * 2.0});
+    }
+}
+
 // Workgroup-wide loads: ONE wave-instruction fetches a whole KiB of a narrow operand for the workgroup (lane-contiguous 16 B per lane), the
 // cells reach the four waves through LDS behind a workgroup barrier.  The direct form reads the same KiB as eight 128-byte requests from four
 // waves; the question is whether the DRAM interface likes a write stream interrupted by a few long reads better than by many short ones.
@@ -717,6 +742,24 @@ int main(int argc, char** argv) {
     ST(2, 4, false, 4, 1, 1, 64, false)
     ST(2, 4, false, 1, 1, 1, 64, false)
     ST(2, 4, false, 0, 1, 1, 64, false)
+#elif EC_STORE_SWEEP == 7
+#define SW(U, WAVES, POL, LDSKB)                                                                                                       \
+    if (n % (size_t(WAVES) * 128 * U) == 0 && (n / (size_t(WAVES) * 128 * U)) % 2 == 0) {                                              \
+        char nm[160];                                                                                                                  \
+        snprintf(nm, sizeof nm, "sca U%d x%dw wide-loads+LDS %s 2fronts lds%dK", U, WAVES, polname[POL], LDSKB);                       \
+        const size_t tiles = n / (size_t(WAVES) * 128 * U);                                                                            \
+        vs.push_back(Variant{nm, [=](int i) { k_sca_wide<U, WAVES, POL, LDSKB><<<unsigned(tiles), WAVES * 64>>>(a[i % SETS], (D2*)out[i & 1], tiles); }, 9.0 * double(n), false, {}}); \
+    }
+    WG(4, true, false)
+    SW(2, 4, 4, 0) SW(2, 4, 4, 16) SW(2, 4, 4, 24)
+    SW(4, 4, 4, 0) SW(4, 4, 4, 16) SW(4, 4, 4, 24) SW(4, 4, 4, 32) SW(4, 4, 4, 40) SW(4, 4, 4, 48) SW(4, 4, 4, 64)
+    SW(8, 4, 4, 0) SW(8, 4, 4, 16) SW(8, 4, 4, 24) SW(8, 4, 4, 32) SW(8, 4, 4, 40) SW(8, 4, 4, 48) SW(8, 4, 4, 64) SW(8, 4, 4, 96)
+    SW(8, 2, 4, 0) SW(8, 2, 4, 16) SW(8, 2, 4, 24) SW(8, 2, 4, 32) SW(8, 2, 4, 48)
+    SW(4, 2, 4, 16) SW(4, 2, 4, 24) SW(4, 2, 4, 32)
+    SW(8, 1, 4, 8) SW(8, 1, 4, 12) SW(8, 1, 4, 16) SW(8, 1, 4, 24)
+    SW(8, 4, 1, 48) SW(8, 4, 1, 32)
+    vs.push_back(Variant{"sca LIB k_binop_scalar_direct<u8, Mul, 2> without the NaN rule (what the library launches), all loads nt",
+                         [=](int i) { k_binop_scalar_direct<uint8_t, EC_MUL, 2, true, true, false><<<unsigned((n / 2 + 511) / 512), 256>>>(a[i % SETS], 2.0, out[i & 1], n, 0u); }, 9.0 * double(n), false, {}});
 #elif EC_STORE_SWEEP == 3
     SWEEP3
 #else
