@@ -183,6 +183,38 @@ __global__ __launch_bounds__(WAVES * 64) void k_sca_wide(const uint8_t* __restri
     }
 }
 
+// Eighth sweep: the mix with 16 bytes per lane of BOTH operands in flight per wave — a wave tile of 1024 cells: one dwordx4 of the u8 operand,
+// two of the u16 operand, 8 KiB of output in eight stores — so that the few resident waves the store stream likes (fill: 2 workgroups per CU,
+// 0.95) still carry the ~12 KB per CU of loads the read stream needs.  Stores without a "memory" clobber, as the library's (ec_device.hpp).
+__device__ __forceinline__ void store16_free(D2* p, D2 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(v)); }
+template <int WAVES, int LDSKB, bool CLOBBER>
+__global__ __launch_bounds__(WAVES * 64) void k_mix_wide8(const uint8_t* __restrict__ l, const uint16_t* __restrict__ r, D2* __restrict__ op, size_t tiles) {
+    reserve_lds<LDSKB>();
+    __shared__ __attribute__((aligned(16))) unsigned char slab_a[WAVES][1024];
+    __shared__ __attribute__((aligned(16))) unsigned char slab_b[WAVES][2048];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t b = blockIdx.x, tile = (b & 1) ? tiles - 1 - (b >> 1) : (b >> 1);
+    const size_t cell0 = (tile * WAVES + wave) * 1024;
+    const u32x4 av = nt_load(reinterpret_cast<const u32x4*>(l + cell0) + lane);
+    const u32x4 bv0 = nt_load(reinterpret_cast<const u32x4*>(r + cell0) + lane);
+    const u32x4 bv1 = nt_load(reinterpret_cast<const u32x4*>(r + cell0) + 64 + lane);
+    reinterpret_cast<u32x4*>(slab_a[wave])[lane] = av;
+    reinterpret_cast<u32x4*>(slab_b[wave])[lane] = bv0;
+    reinterpret_cast<u32x4*>(slab_b[wave])[64 + lane] = bv1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    D2* o2 = op + cell0 / 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint16_t a2 = reinterpret_cast<const uint16_t*>(slab_a[wave])[j * 64 + lane];
+        const uint32_t b2 = reinterpret_cast<const uint32_t*>(slab_b[wave])[j * 64 + lane];
+        const D2 o = D2{double(a2 & 0xffu) + double(b2 & 0xffffu), double(a2 >> 8) + double(b2 >> 16)};
+        if constexpr (CLOBBER) store16<4>(o2 + j * 64 + lane, o);
+        else store16_free(o2 + j * 64 + lane, o);
+    }
+}
+
 // Workgroup-wide loads: ONE wave-instruction fetches a whole KiB of a narrow operand for the workgroup (lane-contiguous 16 B per lane), the
 // cells reach the four waves through LDS behind a workgroup barrier.  The direct form reads the same KiB as eight 128-byte requests from four
 // waves; the question is whether the DRAM interface likes a write stream interrupted by a few long reads better than by many short ones.
@@ -760,6 +792,22 @@ int main(int argc, char** argv) {
     SW(8, 4, 1, 48) SW(8, 4, 1, 32)
     vs.push_back(Variant{"sca LIB k_binop_scalar_direct<u8, Mul, 2> without the NaN rule (what the library launches), all loads nt",
                          [=](int i) { k_binop_scalar_direct<uint8_t, EC_MUL, 2, true, true, false><<<unsigned((n / 2 + 511) / 512), 256>>>(a[i % SETS], 2.0, out[i & 1], n, 0u); }, 9.0 * double(n), false, {}});
+#elif EC_STORE_SWEEP == 8
+    ST(2, 4, false, 4, 1, 1, 0, true)
+#define M8(WAVES, LDSKB, CLOBBER)                                                                                                      \
+    if (n % (size_t(WAVES) * 1024) == 0 && (n / (size_t(WAVES) * 1024)) % 2 == 0) {                                                    \
+        char nm[160];                                                                                                                  \
+        snprintf(nm, sizeof nm, "mix U8 x%dw 16B/lane loads+LDS nt+sc1%s 2fronts lds%dK", WAVES, CLOBBER ? "" : " (no clobber)", LDSKB); \
+        const size_t tiles = n / (size_t(WAVES) * 1024);                                                                               \
+        add(nm, true, [=](int i) { k_mix_wide8<WAVES, LDSKB, CLOBBER><<<unsigned(tiles), WAVES * 64>>>(a[i % SETS], b[i % SETS], (D2*)out[i & 1], tiles); }); \
+    }
+    M8(4, 0, false) M8(4, 16, false) M8(4, 24, false) M8(4, 32, false) M8(4, 40, false) M8(4, 48, false) M8(4, 64, false)
+    M8(2, 0, false) M8(2, 8, false) M8(2, 16, false) M8(2, 24, false) M8(2, 32, false)
+    M8(1, 0, false) M8(1, 4, false) M8(1, 8, false) M8(1, 12, false) M8(1, 16, false)
+    M8(4, 32, true) M8(2, 16, true)
+    MW(4, 4, 4, 32) MW(4, 4, 4, 24)
+    vs.push_back(Variant{"mix LIB k_binop_direct<u8, u16, Add, 2> (the library's kernel), all loads nt",
+                         [=](int i) { k_binop_direct<uint8_t, uint16_t, EC_ADD, 2, true, true><<<unsigned((n / 2 + 511) / 512), 256>>>(a[i % SETS], b[i % SETS], out[i & 1], n, 0u); }, 11.0 * double(n), false, {}});
 #elif EC_STORE_SWEEP == 3
     SWEEP3
 #else
