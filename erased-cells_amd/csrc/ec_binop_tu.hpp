@@ -27,16 +27,30 @@ static ec_status launch_binop_pair(const void* l, const void* r, size_t n, doubl
         return check_launch("binop(cellwise)");
     }
     constexpr bool kCanStage = Staged<L>::value || Staged<R>::value;
-    if (kCanStage && tu.binop_variant == 1) {
-        const size_t tiles = (n / kLdsWaveCells + kWavesPerBlock - 1) / kWavesPerBlock;
-        k_binop_lds<L, R, OP, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, 0, s>>>(lp, rp, out, n);
-        return check_launch("binop(lds)");
-    }
-    const unsigned head = peel_head(l, sizeof(L), r, sizeof(R), n);
-    const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
+    const int variant = tu.binop_variant.load();
     const size_t stream_bytes[2] = {n * sizeof(L), l == r ? 0 : n * sizeof(R)};  // l == r: one stream, read twice
     unsigned policy = cache_plan(stream_bytes, 2, n * sizeof(double));
     if (l == r && (policy & 1u)) policy |= 2u;
+    // The LDS-staged variant by RULE (binop_variant = -1, the default): an 8-byte operand against one of <= 4 bytes — the operators of an
+    // eager chain once its first result exists (u16 + f64, f64 * f32) — when no operand is kept cacheable (the staged kernel loads nt).
+    // The narrow operand arrives in one 16-byte load per lane instead of two of 2-8 bytes, and with that the kernel tolerates — wants —
+    // five resident workgroups per CU instead of eight, which is what its 8 B/cell store stream likes (profiles/r04/store_stream.md):
+    // f64 . u16 and u16 . f64 0.80 -> 0.82, f64 . f32 0.785 -> 0.80 with every byte from HBM (the sweeps, which peak 1-2 points higher, and
+    // the final A/B: profiles/r04/lds_variant_rule.md).  Every other pair measured at or below the direct kernel and stays there.
+    constexpr bool kRulePair = kCanStage && ((sizeof(L) == 8) != (sizeof(R) == 8)) && (sizeof(L) <= 4 || sizeof(R) <= 4);
+    const bool by_rule = variant < 0 && kRulePair && policy == 0 && n >= (size_t(1) << 20);
+    if (kCanStage && (variant == 1 || by_rule)) {
+        const size_t tiles = (n / kLdsWaveCells + kWavesPerBlock - 1) / kWavesPerBlock;
+        // five workgroups per CU: 160 KiB of LDS in granules of 1280 bytes -> at most 32000 bytes per workgroup, slabs included
+        constexpr unsigned kStatic = kWavesPerBlock * unsigned(Staged<L>::kSlabBytes + Staged<R>::kSlabBytes);
+        const int knob = tu.binop_lds_kb.load();
+        const unsigned lds = knob >= 0 ? unsigned(knob) << 10 : by_rule ? 32000u - kStatic : 0u;
+        k_binop_lds<L, R, OP, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, lds, s>>>(lp, rp, out, n);
+        if (by_rule) lds_rule_launches().fetch_add(1, std::memory_order_relaxed);
+        return check_launch(by_rule ? "binop(lds, by rule)" : "binop(lds)");
+    }
+    const unsigned head = peel_head(l, sizeof(L), r, sizeof(R), n);
+    const size_t tiles = (((n - head) >> 1) + size_t(kBlock) * U - 1) / (size_t(kBlock) * U);
     k_binop_direct<L, R, OP, U, kNtStore, kNtLoad><<<grid_for(tiles), kBlock, lds_cap(tuning().binop_lds_kb.load(), sizeof(L) == 8 && sizeof(R) == 8 ? 48 : 0), s>>>(lp, rp, out, n, head | (policy << 8));
     return check_launch("binop(direct)");
 }
@@ -55,7 +69,7 @@ static ec_status launch_masked_pair(const void* l, const uint8_t* lm, const void
     constexpr bool kCanStage = Staged<L>::value || Staged<R>::value;
     if (kCanStage && tu.binop_variant == 1) {
         const size_t tiles = (n / kLdsWaveCells + kWavesPerBlock - 1) / kWavesPerBlock;
-        k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, true><<<grid_for(tiles), kBlock, 0, s>>>(lp, lm, rp, rm, out, om, n, 0u);
+        k_masked_binop<L, R, OP, U, kNtStore, kNtLoad, true><<<grid_for(tiles), kBlock, lds_cap(tu.binop_lds_kb.load(), 0), s>>>(lp, lm, rp, rm, out, om, n, 0u);
         return check_launch("masked_binop(lds)");
     }
     const unsigned head = peel_head(l, sizeof(L), r, sizeof(R), n);

@@ -108,6 +108,8 @@ static std::map<int, DeviceState> g_devs;
 static std::atomic<int> g_default_device{-1};
 static std::atomic<uint64_t> g_generation{1};  // bumped by ec_shutdown: invalidates every thread's cached binding
 static std::atomic<uint64_t> g_stamp{0};
+static std::atomic<int64_t> g_lds_rule_launches{0};
+std::atomic<int64_t>& lds_rule_launches() { return g_lds_rule_launches; }
 static std::atomic<int64_t> g_pool_allocs{0};  // ec_alloc_async calls that reached the pool (ec_stat_get)
 static Tuning g_tuning;
 
@@ -464,6 +466,7 @@ extern "C" ec_status ec_stream_sync(ec_stream s) { return check_hip(hipStreamSyn
 extern "C" ec_status ec_stat_get(const char* key, int64_t* value) {
     if (!key || !value) return set_error(EC_ERR_ARG, "ec_stat_get: null argument");
     if (!std::strcmp(key, "pool_allocs")) *value = g_pool_allocs.load(std::memory_order_relaxed);
+    else if (!std::strcmp(key, "binop_lds_rule_launches")) *value = g_lds_rule_launches.load(std::memory_order_relaxed);
     else if (!std::strncmp(key, "tune.", 5)) {  // the current value of a knob of ec_tune_set, so that a caller can put it back
         const char* k = key + 5;
         if (!std::strcmp(k, "binop_variant")) *value = g_tuning.binop_variant;

@@ -34,7 +34,7 @@ Tuning& tuning();
 // Process-wide knobs (ec_tune_set).  Each field is an atomic word: a knob may be turned while other host threads
 // launch — a launch sees the old or the new value of each knob, never a torn one; both are valid launch shapes.
 struct Tuning {
-    std::atomic<int> binop_variant{0};  // 0 = direct narrow loads, 1 = LDS-staged narrow operands
+    std::atomic<int> binop_variant{-1};  // -1 = by rule (ec_binop_tu.hpp: LDS-staged for an 8-byte operand against one of <= 4 bytes), 0 = always direct narrow loads, 1 = LDS-staged wherever an operand can be staged
     std::atomic<int> reduce_bpc{0};     // workgroups per CU for reductions; 0 = each launch shape's own default (4 x 512 threads)
     std::atomic<int> reduce_shape{0};   // min_max launch shape A/B (ec_abi.hip launch_min_max): 0 = 512 thr x 8 loads (default)
     std::atomic<int> map_u{2};          // 16-B groups per lane per tile for the map kernels (1, 2 or 4)
@@ -79,6 +79,7 @@ ec_status set_error(ec_status code, const char* fmt, ...);
 ec_status set_error_text(ec_status code, const std::string& text);
 const std::string& last_error_text();
 ec_status set_narrowing(int src, int dst);
+std::atomic<int64_t>& lds_rule_launches();  // binop launches that took the LDS-staged variant by rule (ec_stat_get "binop_lds_rule_launches")
 ec_status check_launch(const char* what);
 ec_status check_hip(hipError_t e, const char* what);
 

@@ -466,7 +466,7 @@ ec_status ec_synth_fill(ec_dtype t, void *dst, size_t n, uint64_t seed, uint64_t
 ec_status ec_synth_mask(uint8_t *dst, size_t n, uint64_t seed, uint64_t base, uint32_t pct_nodata, ec_stream stream);
 /* Tuning knobs (each an atomic word: may be set while other host threads launch): "pool_keep_mb" (release threshold
  * of the library's stream-ordered pools), "fused_mixed" (1, default: one-pass kernels for fused chains over mixed
- * cell types; 0: convert to the union type first), "binop_variant" (0 direct narrow loads, 1 LDS-staged), "reduce_bpc" (workgroups per CU for reductions; 0, default: as many as are resident at once), "reduce_shape" (A/B launch shapes of min_max, 0 default),
+ * cell types; 0: convert to the union type first), "binop_variant" (-1, default: by rule — LDS-staged for an 8-byte operand against one of <= 4 bytes on large rasters; 0 always direct narrow loads; 1 LDS-staged wherever an operand can be staged), "reduce_bpc" (workgroups per CU for reductions; 0, default: as many as are resident at once), "reduce_shape" (A/B launch shapes of min_max, 0 default),
  * "map_u" (16-B groups per lane per tile of the map kernels: 1, 2 or 4), "unaligned_vector" (1, default: vector
  * kernels at any cell offset via unaligned global access; 0: pointers that are not 16-byte aligned run the
  * one-cell-per-lane kernels), "peel" (leading-cell peel of the binop/fused kernels at odd offsets: 0 off, 1 for

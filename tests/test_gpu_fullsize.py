@@ -63,7 +63,7 @@ def test_config2_divide_u8_u16_16384sq_bit_exact(ec):
             mn, mx = out.min_max()
             assert (mn.value, mx.value) == (exp.min(), exp.max())
         finally:
-            L.ec_tune_set(b"binop_variant", 0)
+            L.ec_tune_set(b"binop_variant", -1)  # the default: by rule
     # the 8 row-block shards of §8e, computed separately, tile the same result
     from erased_cells_hip import sharded
     for g in (0, 3, 7):

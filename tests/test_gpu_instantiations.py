@@ -71,7 +71,7 @@ def test_binop_and_masked_binop_every_pair(ec, pool, variant, vector, off):
                     got = dev[lt].shard(off, N)._binop(op, 3)
                     assert_f64_bits_equal(got.to_numpy(), eco.f_binop_scalar(op, host[lt][off:off + N], eco.Value.of(eco.I32, 3)))
     finally:
-        L.ec_tune_set(b"binop_variant", 0)
+        L.ec_tune_set(b"binop_variant", -1)  # the default: by rule
         L.ec_tune_set(b"unaligned_vector", 1)
 
 

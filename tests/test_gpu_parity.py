@@ -65,9 +65,9 @@ def test_binop_all_pairs_bit_exact(ec, lct):
             assert_f64_bits_equal(got.to_numpy(), exp, nan_by_class_where=loose)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [-1, 0, 1])
 def test_binop_reference_shaped_oracle_and_variants(ec, variant):
-    """Both kernel variants (direct / LDS-staged) against the reference-shaped oracle."""
+    """Both kernel variants (direct / LDS-staged; -1: the library's own choice) against the reference-shaped oracle."""
     ec.lib().ec_tune_set(b"binop_variant", variant)
     try:
         n = 3000
@@ -79,7 +79,7 @@ def test_binop_reference_shaped_oracle_and_variants(ec, variant):
                 loose = _both_nan(l, r) if op in (eco.ADD, eco.MUL) else None
                 assert_f64_bits_equal(got, eco.binop(op, l, r), nan_by_class_where=loose)
     finally:
-        ec.lib().ec_tune_set(b"binop_variant", 0)
+        ec.lib().ec_tune_set(b"binop_variant", -1)  # the default: by rule
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -106,7 +106,64 @@ def test_binop_lengths_tails_and_alignment(ec, ua, variant):
         e = dl.shard(0, 0) + dr
         assert e.cell_type() == ec.UInt8 and e.len() == 0
     finally:
-        ec.lib().ec_tune_set(b"binop_variant", 0)
+        ec.lib().ec_tune_set(b"binop_variant", -1)  # the default: by rule
+
+
+def test_binop_lds_staged_variant_by_rule(ec):
+    """An 8-byte operand against one of <= 4 bytes, a million cells or more, nothing kept cacheable: the library takes the LDS-staged
+    kernel under an occupancy cap by itself (ec_binop_tu.hpp).  Same cells as the oracle, ragged tail included, and the counter says
+    the rule fired; below the size threshold, with the knob at 0, and for pairs outside the rule it does not."""
+    L = ec.lib()
+    import ctypes as C
+    def launches():
+        v = C.c_int64()
+        ec._ffi.check(L.ec_stat_get(b"binop_lds_rule_launches", C.byref(v)))
+        return v.value
+    n = (1 << 20) + 777
+    pairs = [(eco.F64, eco.U16), (eco.U16, eco.F64), (eco.F64, eco.F32), (eco.F32, eco.F64), (eco.F64, eco.U8), (eco.I8, eco.F64),
+             (eco.I64, eco.U32), (eco.I16, eco.U64)]
+    # operands this small would be kept cacheable (they fit the Infinity Cache) and the rule leaves those launches to the direct kernel:
+    # a cache budget of 0 gives these megabyte-sized buffers the load policy of the gigabyte-sized ones the rule is for
+    mall = C.c_int64()
+    ec._ffi.check(L.ec_stat_get(b"tune.mall_mb", C.byref(mall)))
+    L.ec_tune_set(b"mall_mb", 0)
+    try:
+        _lds_rule_cases(ec, L, launches, n, pairs)
+    finally:
+        L.ec_tune_set(b"mall_mb", mall.value)
+    l, r = rand_cells(eco.F64, n, 35), rand_cells(eco.U16, n, 36)
+    before = launches()
+    got = (ec.CellBuffer.from_vec(l) * ec.CellBuffer.from_vec(r)).to_numpy()  # cacheable operands: the direct kernel
+    assert launches() == before
+    assert_f64_bits_equal(got, eco.f_binop(eco.MUL, l, r), nan_by_class_where=_both_nan(l, r))
+
+
+def _lds_rule_cases(ec, L, launches, n, pairs):
+    for lct, rct in pairs:
+        l, r = rand_cells(lct, n, 31), rand_cells(rct, n, 32)
+        dl, dr = ec.CellBuffer.from_vec(l), ec.CellBuffer.from_vec(r)
+        for op in OPS:
+            before = launches()
+            got = dl._binop(op, dr).to_numpy()
+            assert launches() == before + 1, (lct, rct, op)
+            loose = _both_nan(l, r) if op in (eco.ADD, eco.MUL) else None
+            assert_f64_bits_equal(got, eco.f_binop(op, l, r), nan_by_class_where=loose)
+        before = launches()
+        small = dl.shard(0, (1 << 20) - 1) + dr.shard(0, (1 << 20) - 1)  # below the threshold: the direct kernel
+        assert launches() == before and small.len() == (1 << 20) - 1
+        L.ec_tune_set(b"binop_variant", 0)
+        try:
+            got0 = (dl / dr).to_numpy()
+        finally:
+            L.ec_tune_set(b"binop_variant", -1)
+        assert launches() == before
+        assert_f64_bits_equal(got0, eco.f_binop(eco.DIV, l, r))
+    for lct, rct in [(eco.F64, eco.F64), (eco.U8, eco.U16), (eco.F32, eco.F32), (eco.U16, eco.U32)]:  # outside the rule
+        l, r = rand_cells(lct, n, 33), rand_cells(rct, n, 34)
+        before = launches()
+        got = (ec.CellBuffer.from_vec(l) - ec.CellBuffer.from_vec(r)).to_numpy()
+        assert launches() == before
+        assert_f64_bits_equal(got, eco.f_binop(eco.SUB, l, r))
 
 
 def test_div_by_zero_and_nan_policy(ec):
@@ -302,7 +359,7 @@ def test_masked_binop_fused(ec, ua, variant):
                               nan_by_class_where=_both_nan(l[1:2001], r[3:2003]))
         assert np.array_equal(got.mask().to_numpy(), lm[1:2001] & rm[3:2003])
     finally:
-        ec.lib().ec_tune_set(b"binop_variant", 0)
+        ec.lib().ec_tune_set(b"binop_variant", -1)  # the default: by rule
 
 
 # ---------------------------------------------------------------- Ord / Eq on the device: src/buffer.rs:373-436
@@ -494,7 +551,7 @@ def test_randomised_shapes_types_and_windows(ec, ua):
     try:
         run()
     finally:
-        ec.lib().ec_tune_set(b"binop_variant", 0)
+        ec.lib().ec_tune_set(b"binop_variant", -1)  # the default: by rule
 
 
 @pytest.mark.parametrize("map_u,reduce_bpc,reduce_shape", [(1, 1, 0), (4, 16, 1), (2, 3, 2), (2, 0, 3), (2, 0, 4)])
