@@ -175,7 +175,7 @@ static ec_status launch_expr(const ec_dtype* dt, const void* const* p, int32_t n
         default: kern = expr_kernel<8>(cls[1], cls[2], cls[3]); break;
     }
     if (!kern) return set_error(EC_ERR_ARG, "%s: no kernel for stream classes %d %d %d %d", what, cls[0], cls[1], cls[2], cls[3]);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, ea, out, out_mask, n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), static_cast<unsigned>(tuning().fused_lds_kb.load()) << 10, s, ea, out, out_mask, n);
     return check_launch("expr");
 }
 

@@ -150,7 +150,7 @@ ec_status expr_fixed_launch(const ExprArgs& ea, size_t n, double* out, uint8_t* 
     if (!kern) return EC_OK;
     const size_t per_tile = size_t(kBlock) * kFixedU;
     const unsigned grid = grid_for((((n - ea.head) >> 1) + per_tile - 1) / per_tile);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, ea, fm, out, out_mask, n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), static_cast<unsigned>(tuning().fused_lds_kb.load()) << 10, s, ea, fm, out, out_mask, n);
     g_fixed_launches.fetch_add(1, std::memory_order_relaxed);
     *launched = true;
     return EC_OK;

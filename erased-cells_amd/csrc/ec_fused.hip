@@ -50,7 +50,7 @@ static ec_status launch_fused_any(FusedArgs& fa, int nops, size_t n, double* out
         default: kern = fused_any_kernel<8>(cls[1], cls[2], cls[3]); break;
     }
     if (!kern) return set_error(EC_ERR_ARG, "ec_fused: no kernel for load classes %d %d %d %d", cls[0], cls[1], cls[2], cls[3]);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, s, fa, out, out_mask, n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), static_cast<unsigned>(tuning().fused_lds_kb.load()) << 10, s, fa, out, out_mask, n);
     return check_launch("fused(any)");
 }
 

@@ -480,6 +480,7 @@ extern "C" ec_status ec_stat_get(const char* key, int64_t* value) {
         else if (!std::strcmp(k, "expr_jit")) *value = g_tuning.expr_jit;
         else if (!std::strcmp(k, "expr_fixed")) *value = g_tuning.expr_fixed;
         else if (!std::strcmp(k, "write_lds_kb")) *value = g_tuning.write_lds_kb;
+        else if (!std::strcmp(k, "fused_lds_kb")) *value = g_tuning.fused_lds_kb;
         else if (!std::strcmp(k, "counts_one_launch")) *value = g_tuning.counts_one_launch;
         else if (!std::strcmp(k, "cache_force")) *value = g_tuning.cache_force;
         else if (!std::strcmp(k, "pool_keep_mb")) *value = g_tuning.pool_keep_mb;
@@ -515,6 +516,7 @@ extern "C" ec_status ec_tune_set(const char* key, int64_t value) {
     else if (!std::strcmp(key, "inject_pin_refusal")) g_tuning.inject_pin_refusal = value != 0;
     else if (!std::strcmp(key, "expr_fixed")) g_tuning.expr_fixed = value != 0;
     else if (!std::strcmp(key, "write_lds_kb")) g_tuning.write_lds_kb = value < 0 ? 0 : value > 64 ? 64 : static_cast<int>(value);
+    else if (!std::strcmp(key, "fused_lds_kb")) g_tuning.fused_lds_kb = value < 0 ? 0 : value > 64 ? 64 : static_cast<int>(value);
     else if (!std::strcmp(key, "binop_lds_kb")) g_tuning.binop_lds_kb = value < 0 ? -1 : value > 64 ? 64 : static_cast<int>(value);
     else if (!std::strcmp(key, "scalar_lds_kb")) g_tuning.scalar_lds_kb = value < 0 ? -1 : value > 64 ? 64 : static_cast<int>(value);
     else if (!std::strcmp(key, "map_lds_kb")) g_tuning.map_lds_kb = value < 0 ? 0 : value > 64 ? 64 : static_cast<int>(value);

@@ -63,6 +63,7 @@ struct Tuning {
     std::atomic<int> binop_lds_kb{-1};
     std::atomic<int> scalar_lds_kb{-1};
     std::atomic<int> map_lds_kb{0};     // experiment knob for the map launches that load (convert, neg, mask_select …): no rule adopted
+    std::atomic<int> fused_lds_kb{0};   // the same reservation for the one-pass kernels (k_fused_any, k_expr, k_expr_fixed): an experiment knob (profiles/r04/fused_caps.md)
     std::atomic<int> counts_one_launch{1};  // Mask::counts in ONE launch: every workgroup adds (1 << 40 | its count) to one 64-bit word of the stream's
                                             // scratch with a returning atomic, the workgroup that reads grid - 1 in the upper bits owns the total,
                                             // writes the result and zeroes the word — one device-scope round trip behind the last load instead of a
