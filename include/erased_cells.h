@@ -470,11 +470,14 @@ ec_status ec_synth_mask(uint8_t *dst, size_t n, uint64_t seed, uint64_t base, ui
  * "map_u" (16-B groups per lane per tile of the map kernels: 1, 2 or 4), "unaligned_vector" (1, default: vector
  * kernels at any cell offset via unaligned global access; 0: pointers that are not 16-byte aligned run the
  * one-cell-per-lane kernels), "peel" (leading-cell peel of the binop/fused kernels at odd offsets: 0 off, 1 for
- * 1-byte operands (default), 2 also for 2-byte operands). */
+ * 1-byte operands (default), 2 also for 2-byte operands).  Measurement knobs (defaults are what ships): "mall_mb",
+ * "cache_force", "expr_jit", "expr_fixed", "counts_one_launch", and the occupancy caps "write_lds_kb", "binop_lds_kb", "scalar_lds_kb",
+ * "map_lds_kb", "fused_lds_kb" (KiB of unused LDS reserved per workgroup of a kernel family). */
 ec_status ec_tune_set(const char *key, int64_t value);
 /* Counters for tests: "pool_allocs" (ec_alloc_async calls so far, including those the library makes itself — a call
  * that leaves it unchanged allocated nothing), "devices" (initialised devices), "scratch_streams" (streams the
- * library currently holds reduction scratch for); "tune.<knob>": the current value of a knob of ec_tune_set (so that a
+ * library currently holds reduction scratch for), "binop_lds_rule_launches", "expr_fixed_launches", "expr_interp_launches",
+ * "expr_jit_launches" (which kernel form a call took); "tune.<knob>": the current value of a knob of ec_tune_set (so that a
  * scope that turns one can put the previous value back). */
 ec_status ec_stat_get(const char *key, int64_t *value);
 
