@@ -35,6 +35,8 @@ WORKLOADS = {
     "evi_fused_compiled": (14, 6, ["ec_expr_jit"]),
     "evi_fused_builtin": (14, 6, ["k_expr_fixed"]),
     "evi": (130, 66, ["k_binop_direct", "k_binop_scalar"]),
+    "binop_add_f64_u16_rule": (18, 10, ["k_binop_lds"]),      # the LDS-staged kernel by rule (round 4)
+    "binop_add_f64_u16_direct": (18, 10, ["k_binop_direct"]),  # the same launch with binop_variant = 0
 }
 TRAFFIC_KEY = {"div": "binop_div_u8_u16"}
 
