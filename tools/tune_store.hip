@@ -18,7 +18,7 @@
 // Infinity Cache).  Reference points: the runtime's own fill (`hipMemsetD32Async`) and a pure 16 B/lane read.
 // Variants run in randomised order over interleaved rounds; every variant's output is checksummed (all must agree).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ierased-cells_amd/csrc tools/tune_store.hip -o tools/tune_store
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 [-DEC_STORE_SWEEP=1..8] -Iinclude -Ierased-cells_amd/csrc tools/tune_store.hip -o tools/tune_store
 //   ./tools/tune_store [side=16384] [rounds=9] [iters=10] [only=<substring of a variant's name>]
 // With `only` the program runs just the matching variants (no shuffling) — the form used directly after
 // `rocprofv3 --pmc … --` for the write-credit-stall / request-level counters (tools/jobs/r04store.sh).
